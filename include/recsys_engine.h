@@ -1,0 +1,146 @@
+/* C ABI of the MI355X engine for the BPR-SGD step and the full-catalog evaluation of the
+ * sequential recommenders of visiativ-innovation/recommendation.
+ *
+ * The reference has no FFI: its seam is the C++ class API (src/model.hpp:9-92 and the per-model
+ * classes in src/models/).  Each entry point below names the reference member(s) it replaces.
+ * Plain pointers and sizes only; every function returns 0 on success and a negative code on
+ * failure, with a message available from rec_last_error().  Nothing throws across this boundary.
+ *
+ * Threading: calls on one rec_engine must not overlap.  rec_sgd_epoch and rec_sgd_replay in
+ * Hogwild mode only enqueue work on the engine's private HIP stream; every other call waits
+ * for that stream first, and rec_sync waits explicitly. */
+#ifndef RECSYS_ENGINE_H
+#define RECSYS_ENGINE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rec_engine rec_engine;
+
+/* CLI model names of src/main.cpp:188-212 */
+enum rec_model {
+    REC_MP = 0, REC_BPRMF = 1, REC_MC = 2, REC_FPMC = 3, REC_PRME = 4, REC_HRM_AVG = 5,
+    REC_HRM_MAX = 6, REC_TRANSREC = 7, REC_TRANSREC_L1 = 8, REC_FOSSIL_SIMPLE = 9,
+    REC_FOSSIL = 10, REC_REBUS = 11
+};
+
+enum rec_precision { REC_F32 = 0, REC_F64 = 1 };
+
+/* How rec_sgd_replay applies the tuples */
+enum rec_replay_mode {
+    REC_REPLAY_SEQUENTIAL = 0, /* deterministic batch-1: one wavefront, tuples strictly in order,
+                                  in-place semantics of the reference's updateFactors */
+    REC_REPLAY_HOGWILD = 1     /* one wavefront (or sub-wavefront lane group) per tuple, float-atomic scatter */
+};
+
+/* What the model constructor leaves behind (src/model.hpp:12-53): the post-split training
+ * sequences corp->pos_per_user (items only, chronological) and test_per_user / val_per_user.
+ * All arrays are copied by rec_create; no host pointer is kept. */
+typedef struct {
+    int32_t n_users, n_items;
+    const int64_t* seq_off;   /* [n_users+1] */
+    const int32_t* seq_item;  /* [seq_off[n_users]] */
+    const int32_t* test_item; /* [n_users], -1 = user without validation/test items */
+    const int32_t* val_item;  /* [n_users] */
+    /* REBUS only (NULL otherwise): the matched path of REBUS::findPathStars for every context.
+     * The context of user u with a prefix of c items (c = 1..n_u+1) has index
+     * seq_off[u] + 2*u + (c-1); c <= n_u-1 are the training positions (histo_user,
+     * REBUS.cpp:132-153), c = n_u the validation and c = n_u+1 the test context
+     * (REBUS.cpp:758-782).  rec_rebus_build_paths produces it. */
+    const int64_t* path_off;  /* [seq_off[n_users] + 2*n_users + 1] */
+    const int32_t* path_item;
+} rec_corpus;
+
+/* Constructor arguments of the model classes plus the constants the reference hard-codes */
+typedef struct {
+    int32_t model;            /* enum rec_model */
+    int32_t K, KK, L;         /* KK = K in src/main.cpp:197,203 */
+    double lambda, bias_reg, relation_reg;
+    double alpha;             /* PRME alpha / REBUS alpha_up (CLI argument 10) */
+    int32_t dataset_factor;   /* Fossil.hpp:22; 0 selects the reference's 10 */
+    int32_t precision;        /* enum rec_precision: storage and arithmetic type of the SGD step */
+    int32_t device;           /* HIP device ordinal */
+    int32_t user_begin, user_end; /* users this engine samples and evaluates; 0,0 = all */
+} rec_model_desc;
+
+/* Outputs of model::AUC (src/model.cpp:3-98) */
+typedef struct {
+    double auc_val, auc_test, hit_val, hit_test, mrr_val, mrr_test, var_test;
+    int64_t n_users; /* users with a test item in [user_begin, user_end) */
+} rec_metrics;
+
+const char* rec_last_error(void);
+
+/* replaces: model ctor's outputs + <Model>::init's allocation (e.g. BPRMF.cpp:3-9) */
+int rec_create(const rec_corpus* corpus, const rec_model_desc* desc, rec_engine** out);
+int rec_destroy(rec_engine* e);
+int rec_sync(rec_engine* e);
+
+/* NW of the model (e.g. BPRMF.cpp:5); the flat order of W is the reference's and is the saved-model format */
+int64_t rec_nw(const rec_engine* e);
+
+/* replaces: direct writes/reads of model::W (src/model.hpp:60-62; saveModel/loadModel go through it) */
+int rec_params_upload(rec_engine* e, const double* W, int64_t nw);
+int rec_params_download(rec_engine* e, double* W, int64_t nw);
+
+/* replaces: <Model>::init's random fill (e.g. BPRMF.cpp:11-21, TransRec.cpp:14-30) with a
+ * counter-based generator of the same distribution */
+int rec_params_init(rec_engine* e, uint64_t seed);
+
+/* replaces: model::copyBestModel (src/model.cpp:169-174) and the "W <- bestW" loop of train() (e.g. BPRMF.cpp:189-191) */
+int rec_snapshot_best(rec_engine* e);
+int rec_restore_best(rec_engine* e);
+
+/* replaces: n consecutive <Model>::updateFactors calls (e.g. BPRMF.cpp:85-105) on the given
+ * tuples (4 x int32 each):
+ *   BPRMF (u,pos,neg,-)  MC (item,pos,neg,-)  FPMC/PRME/FossilSimple/HRM_* (u,prev,pos,neg)
+ *   TransRec* (u,x,y,yn)  Fossil (u,t,neg,-) and REBUS (u,t-1,neg,-) with target seq[u][t] */
+int rec_sgd_replay(rec_engine* e, double lr, const int32_t* tuples, int64_t n, int mode);
+
+/* replaces: <Model>::oneiteration / oneIteration (e.g. BPRMF.cpp:107-150): n_steps tuples drawn on
+ * the device by a counter-based generator keyed by (seed, epoch, step), applied Hogwild-style */
+int rec_sgd_epoch(rec_engine* e, double lr, int64_t n_steps, uint64_t seed, uint64_t epoch);
+
+/* the sampler alone (tests, tuple capture): writes n tuples (4 x int32) to host memory */
+int rec_sample_tuples(rec_engine* e, int64_t n, uint64_t seed, uint64_t epoch, int32_t* tuples_out);
+
+/* number of updateFactors calls per epoch: num_pos_events (src/model.hpp:47-51), MC: num_pos_trans (MC.cpp:19-22) */
+int64_t rec_steps_per_epoch(const rec_engine* e);
+
+/* replaces: model::AUC / Fossil::AUC / REBUS::AUC and model::MultipleMetrics (src/model.cpp:3-98,
+ * 239-329).  counts_out (optional): per user count_val, count_test, max (-1,-1,-1 when not
+ * evaluated).  xpos_out (optional): per user x_test, x_val. */
+int rec_eval(rec_engine* e, int topn, rec_metrics* out, int32_t* counts_out, double* xpos_out);
+
+/* Partial sums of rec_eval over this engine's users, for a sum all-reduce across ranks:
+ * {sum AUC_val, AUC_test, HIT_val, HIT_test, MRR_val, MRR_test, sum AUC_test^2, n_users} */
+int rec_eval_sums(rec_engine* e, int topn, double sums[8]);
+
+/* replaces: REBUS::findPathStars over every context (REBUS.cpp:132-153, 484-524, 758-782).
+ * Labels of a 96-FSUB file as integer sequences, oldest item first ("Root" omitted):
+ * lab_off[n_labels+1], lab_item[].  Call with path_item = NULL to obtain the size. Host only. */
+int64_t rec_rebus_build_paths(int32_t n_users, int32_t n_items, const int64_t* seq_off,
+                              const int32_t* seq_item, const int32_t* val_item, int64_t n_labels,
+                              const int64_t* lab_off, const int32_t* lab_item, int64_t* path_off,
+                              int32_t* path_item);
+
+/* Device tables, for collectives issued by the caller (RCCL through torch.distributed):
+ * table t of the model in the reference's flat order.  *dev_ptr points to rows x cols elements
+ * of the engine's precision, contiguous.  is_user_table = 1 for tables indexed by user. */
+int rec_num_tables(const rec_engine* e);
+int rec_table_info(const rec_engine* e, int t, void** dev_ptr, int64_t* rows, int64_t* cols, int* is_user_table);
+
+/* Tuning knobs: "chunk" (tuples per update launch), "atomic" (1 = float atomics, 0 = plain
+ * racy read-modify-write), "profile" (1 = time every update / scoring launch with HIP events) */
+int rec_set_option(rec_engine* e, const char* name, int64_t value);
+
+/* HIP-event statistics gathered while "profile" = 1: which = 0 SGD update kernel, 1 eval scoring
+ * kernel, 2 sampler.  Resets the counters. */
+int rec_kernel_stats(rec_engine* e, int which, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,126 @@
+// Shared between the translation units of librecsys_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "../../include/recsys_engine.h"
+
+#define REC_MAX_TABLES 6
+#define REC_MAX_EPL 4   // elements per lane: K <= 64 * REC_MAX_EPL
+#define REC_MAX_K (64 * REC_MAX_EPL)
+#define REC_MAX_L 32
+
+// Everything a kernel needs to know about the model and the corpus; passed by value.
+struct DevModel {
+    int model, U, I, K, KK, L;
+    double lambda, bias_reg, relation_reg, alpha, df;
+    void* tab[REC_MAX_TABLES];          // device tables in the reference's flat order, rows contiguous
+    const int64_t* seq_off;             // [U+1] training sequences
+    const int32_t* seq_item;
+    const int32_t* test_item;           // [U]
+    const int32_t* val_item;            // [U]
+    const int64_t* clk_off;             // [U+1] sorted distinct training items per user
+    const int32_t* clk_item;
+    const uint8_t* first_occ;           // [E] 1 where a sequence position is the first occurrence of its item
+    const int64_t* path_off;            // REBUS matched paths per context
+    const int32_t* path_item;
+    const double* eta;                  // (L+1) x L damping weights
+    const int32_t* elig;                // users (MC: source items) the sampler may draw
+    int n_elig;
+    const int64_t* succ_off;            // MC: successors of each item with multiplicity ...
+    const int32_t* succ_item;
+    const int64_t* sset_off;            // ... and as sorted distinct sets
+    const int32_t* sset_item;
+    void* gacc;                         // accumulators for rows every tuple touches (TransRec r, Fossil WT, FossilSimple alpha)
+    const int32_t* eval_users;          // users of this engine's shard that have a test item
+    int n_eval;
+    const int32_t* train_count;         // [I] occurrences of each item in the training sequences (MostPopular)
+};
+
+// table indices, in the flat order of each model's getParametersFromVector / parametersToFlatVector
+enum { BPRMF_BETA = 0, BPRMF_GU = 1, BPRMF_GI = 2 };
+enum { MC_GI = 0, MC_ETA = 1 };
+enum { FPMC_GU = 0, FPMC_GI = 1, FPMC_KAPPA = 2, FPMC_ETA = 3 };
+enum { PRME_GU = 0, PRME_GI = 1, PRME_ETA = 2 };
+enum { HRM_U = 0, HRM_V = 1 };
+enum { TR_BETA = 0, TR_H = 1, TR_R = 2, TR_r = 3 };
+enum { FS_ALPHA = 0, FS_ALPHA_U = 1, FS_BETA = 2, FS_UI = 3, FS_V = 4 };
+enum { FO_BETA = 0, FO_WT = 1, FO_WTU = 2, FO_UI = 3, FO_V = 4 };
+enum { RB_BETA = 0, RB_P = 1 };
+
+void rec_set_error(const std::string& msg);
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            rec_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+            return -2;                                                                        \
+        }                                                                                     \
+    } while (0)
+
+// ---- launchers implemented in the kernel translation units (all enqueue on `st`) ----
+int launch_sgd_sequential(const DevModel& m, int precision, const int4* tuples, int64_t n, double lr, hipStream_t st);
+int launch_sgd_hogwild(const DevModel& m, int precision, const int4* tuples, int64_t n, double lr, int atomic,
+                       hipStream_t st);
+int launch_apply_global(const DevModel& m, int precision, double lr, int64_t n_tuples, hipStream_t st);
+int launch_sampler(const DevModel& m, int4* tuples, int64_t n, int64_t first_step, uint64_t seed, uint64_t epoch,
+                   hipStream_t st);
+int launch_convert_in(const double* src, void* dst, int64_t n, int precision, hipStream_t st);
+int launch_convert_out(const void* src, double* dst, int64_t n, int precision, hipStream_t st);
+int launch_param_init(const DevModel& m, int precision, uint64_t seed, hipStream_t st);
+
+// Full-catalog evaluation of the users in m.eval_users.  counts_host: [U][3] (count_val, count_test,
+// max; -1 for users not evaluated); xpos_host (optional): [U][2] (x_test, x_val).
+int eval_run(const DevModel& m, int precision, int32_t* counts_host, double* xpos_host, hipStream_t st,
+             double* score_ms, int64_t* score_launches, bool profile);
+
+#ifdef __HIPCC__
+// ---------------------------------------------------------------- device helpers
+__device__ __forceinline__ float rexp(float x) { return expf(x); }
+__device__ __forceinline__ double rexp(double x) { return exp(x); }
+__device__ __forceinline__ float rpow(float x, float y) { return powf(x, y); }
+__device__ __forceinline__ double rpow(double x, double y) { return pow(x, y); }
+__device__ __forceinline__ float rsqrt_(float x) { return sqrtf(x); }
+__device__ __forceinline__ double rsqrt_(double x) { return sqrt(x); }
+__device__ __forceinline__ float rabs(float x) { return fabsf(x); }
+__device__ __forceinline__ double rabs(double x) { return fabs(x); }
+
+// sum over the lanes of an aligned group of W lanes (W = 16, 32 or 64); every lane gets the sum
+template <int W, class T>
+__device__ __forceinline__ T group_sum(T v)
+{
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Philox4x32-10 (Salmon et al. 2011): counter-based, so a tuple depends only on (seed, epoch, step)
+__device__ __forceinline__ uint4 philox4x32(uint4 ctr, uint2 key)
+{
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
+        uint32_t hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
+        ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+        key.x += W0; key.y += W1;
+    }
+    return ctr;
+}
+
+// uniform integer in [0, n) from 32 random bits (multiply-shift)
+__device__ __forceinline__ uint32_t bounded(uint32_t r, uint32_t n) { return __umulhi(r, n); }
+
+// is `x` in the sorted array a[0..n) ?
+__device__ __forceinline__ bool sorted_contains(const int32_t* a, int n, int32_t x)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        int32_t v = a[mid];
+        if (v < x) lo = mid + 1; else hi = mid;
+    }
+    return lo < n && a[lo] == x;
+}
+#endif

@@ -1,0 +1,549 @@
+// C ABI of librecsys_amd.so: engine life cycle, parameter transfer, dispatch to the kernels.
+#include "common.h"
+#include <algorithm>
+#include <math.h>
+#include <string.h>
+#include <vector>
+
+static thread_local std::string g_err;
+void rec_set_error(const std::string& msg) { g_err = msg; }
+extern "C" const char* rec_last_error(void) { return g_err.c_str(); }
+
+struct TableDesc {
+    int64_t host_off, rows, cols, dev_off;  // offsets in elements
+    int is_user;
+};
+
+struct rec_engine {
+    rec_model_desc desc;
+    int U = 0, I = 0;
+    int64_t E = 0, nw = 0, dev_elems = 0, steps_per_epoch = 0;
+    int elem_size = 4;
+    std::vector<TableDesc> tables;
+    DevModel dm;
+    hipStream_t st = nullptr;
+    void* W = nullptr;       // device parameters (all tables)
+    void* bestW = nullptr;   // copyBestModel snapshot
+    double* stage = nullptr; // f64 staging for upload / download
+    int64_t stage_elems = 0;
+    int4* tuples = nullptr;  // tuple buffer of the current chunk(s)
+    int64_t tuples_cap = 0;
+    std::vector<void*> owned;
+    // options
+    int64_t chunk = 1 << 22;
+    int atomic = 1;
+    int profile = 0;
+    // hip-event statistics: 0 update, 1 score, 2 sampler
+    double ms[3] = {0, 0, 0};
+    int64_t launches[3] = {0, 0, 0};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[3];
+};
+
+static int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+#define ENG_HIP(expr)                                                                 \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess) {                                                       \
+            rec_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));         \
+            return -2;                                                                \
+        }                                                                             \
+    } while (0)
+
+template <class T>
+static int upload(rec_engine* e, const std::vector<T>& h, const T** dev)
+{
+    void* p = nullptr;
+    ENG_HIP(hipMalloc(&p, std::max<size_t>(h.size() * sizeof(T), 8)));
+    e->owned.push_back(p);
+    if (!h.empty()) ENG_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dev = (const T*)p;
+    return 0;
+}
+
+static void build_tables(rec_engine* e)
+{
+    const int64_t U = e->U, I = e->I, K = e->desc.K, KK = e->desc.KK, L = e->desc.L;
+    std::vector<TableDesc>& t = e->tables;
+    auto add = [&](int64_t rows, int64_t cols, int is_user) { t.push_back({0, rows, cols, 0, is_user}); };
+    switch (e->desc.model) {
+    case REC_BPRMF: add(I, 1, 0); add(U, K, 1); add(I, K, 0); break;                       // BPRMF.cpp:49-61
+    case REC_MC: add(I, K, 0); add(I, K, 0); break;                                        // MC.cpp:59-67
+    case REC_FPMC: add(U, K, 1); add(I, K, 0); add(I, KK, 0); add(I, KK, 0); break;        // FPMC.cpp:46-63
+    case REC_PRME: add(U, K, 1); add(I, K, 0); add(I, KK, 0); break;                       // PRME.cpp:43-56
+    case REC_HRM_AVG: case REC_HRM_MAX: add(U, K, 1); add(I, K, 0); break;                 // HRM_avg.cpp:46-56
+    case REC_TRANSREC: case REC_TRANSREC_L1: add(I, 1, 0); add(I, K, 0); add(U, K, 1); add(1, K, 0); break;  // TransRec.cpp:61-77
+    case REC_FOSSIL_SIMPLE: add(1, 1, 0); add(U, 1, 1); add(I, 1, 0); add(I, K, 0); add(I, K, 0); break;     // FossilSimple.cpp:56-74
+    case REC_FOSSIL: add(I, 1, 0); add(1, L, 0); add(U, L, 1); add(I, K, 0); add(I, K, 0); break;            // Fossil.cpp:53-73
+    case REC_REBUS: add(I + 1, 1, 0); add(I + 1, K, 0); break;                             // REBUS.cpp:185-193
+    default: break;  // MP has no parameters
+    }
+    int64_t ho = 0, dv = 0;
+    for (auto& d : t) {
+        d.host_off = ho; d.dev_off = dv;
+        ho += d.rows * d.cols;
+        dv = align_up(dv + d.rows * d.cols, 256 / e->elem_size);  // every table starts on a 256-byte boundary
+    }
+    e->nw = ho; e->dev_elems = std::max<int64_t>(dv, 64);
+}
+
+extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engine** out)
+{
+    if (!c || !d || !out) { rec_set_error("null argument"); return -1; }
+    if (d->model < REC_MP || d->model > REC_REBUS) { rec_set_error("unknown model"); return -1; }
+    if (d->model != REC_MP && (d->K < 1 || d->K > REC_MAX_K)) { rec_set_error("K must be in 1..256"); return -1; }
+    if (d->model == REC_FOSSIL && (d->L < 1 || d->L > REC_MAX_L)) { rec_set_error("L must be in 1..32"); return -1; }
+    if (d->model == REC_REBUS && (!c->path_off || !c->path_item)) { rec_set_error("REBUS needs the matched paths"); return -1; }
+    if (d->model == REC_REBUS && (d->L < 1 || d->L > REC_MAX_L)) { rec_set_error("L must be in 1..32"); return -1; }
+    int ndev = 0;
+    ENG_HIP(hipGetDeviceCount(&ndev));
+    if (d->device < 0 || d->device >= ndev) { rec_set_error("no such HIP device"); return -1; }
+    ENG_HIP(hipSetDevice(d->device));
+
+    rec_engine* e = new rec_engine();
+    e->desc = *d;
+    if (e->desc.KK <= 0) e->desc.KK = e->desc.K;
+    if (e->desc.L <= 0) e->desc.L = 1;
+    if (e->desc.dataset_factor <= 0) e->desc.dataset_factor = 10;
+    e->U = c->n_users; e->I = c->n_items; e->E = c->seq_off[c->n_users];
+    e->elem_size = d->precision == REC_F64 ? 8 : 4;
+    int ub = d->user_begin, ue = d->user_end;
+    if (ub == 0 && ue == 0) ue = e->U;
+    if (ub < 0 || ue > e->U || ub > ue) { delete e; rec_set_error("bad user range"); return -1; }
+    e->desc.user_begin = ub; e->desc.user_end = ue;
+    build_tables(e);
+
+    const int U = e->U, I = e->I; const int64_t E = e->E;
+    const int L = e->desc.L;
+    // ---- host-side derived structures
+    std::vector<int64_t> seq_off(c->seq_off, c->seq_off + U + 1);
+    std::vector<int32_t> seq_item(c->seq_item, c->seq_item + E);
+    std::vector<int32_t> test_item(c->test_item, c->test_item + U), val_item(c->val_item, c->val_item + U);
+    for (int64_t p = 0; p < E; p++)
+        if (seq_item[p] < 0 || seq_item[p] >= I) { delete e; rec_set_error("item id out of range in seq_item"); return -1; }
+    // clicked_per_user (model.hpp:42-44) as sorted distinct arrays, and first-occurrence flags
+    std::vector<int64_t> clk_off(U + 1, 0);
+    std::vector<int32_t> clk_item; clk_item.reserve(E);
+    std::vector<uint8_t> first_occ(E, 0);
+    std::vector<int32_t> train_count(I, 0);
+    {
+        std::vector<std::pair<int32_t, int64_t>> tmp;
+        for (int u = 0; u < U; u++) {
+            tmp.clear();
+            for (int64_t p = seq_off[u]; p < seq_off[u + 1]; p++) { tmp.push_back({seq_item[p], p}); train_count[seq_item[p]]++; }
+            std::sort(tmp.begin(), tmp.end());
+            for (size_t i = 0; i < tmp.size(); i++)
+                if (i == 0 || tmp[i].first != tmp[i - 1].first) { clk_item.push_back(tmp[i].first); first_occ[tmp[i].second] = 1; }
+            clk_off[u + 1] = (int64_t)clk_item.size();
+        }
+    }
+    // users (MC: source items) each sampler may draw, and the number of updateFactors calls per epoch
+    std::vector<int32_t> elig, eval_users;
+    std::vector<int64_t> succ_off, sset_off; std::vector<int32_t> succ_item, sset_item;
+    e->steps_per_epoch = 0;
+    for (int u = 0; u < U; u++) e->steps_per_epoch += seq_off[u + 1] - seq_off[u];  // num_pos_events, model.hpp:47-51
+    if (d->model == REC_MC) {
+        // item_to_vec / item_to_set, MC.cpp:5-22
+        std::vector<std::vector<int32_t>> sv(I);
+        for (int u = 0; u < U; u++)
+            for (int64_t p = seq_off[u]; p + 1 < seq_off[u + 1]; p++) sv[seq_item[p]].push_back(seq_item[p + 1]);
+        succ_off.assign(I + 1, 0); sset_off.assign(I + 1, 0);
+        e->steps_per_epoch = 0;
+        for (int i = 0; i < I; i++) {
+            succ_item.insert(succ_item.end(), sv[i].begin(), sv[i].end());
+            succ_off[i + 1] = (int64_t)succ_item.size();
+            std::vector<int32_t> s = sv[i];
+            std::sort(s.begin(), s.end()); s.erase(std::unique(s.begin(), s.end()), s.end());
+            sset_item.insert(sset_item.end(), s.begin(), s.end());
+            sset_off[i + 1] = (int64_t)sset_item.size();
+            e->steps_per_epoch += (int64_t)sv[i].size();  // num_pos_trans
+            if (!s.empty() && (int)s.size() != I) elig.push_back(i);  // MC.cpp:84
+        }
+    } else {
+        for (int u = ub; u < ue; u++) {
+            const int64_t nu = seq_off[u + 1] - seq_off[u], nd = clk_off[u + 1] - clk_off[u];
+            bool ok = false;
+            switch (d->model) {
+            case REC_BPRMF: ok = nd > 0 && nd < I; break;                                   // BPRMF.cpp:78
+            case REC_HRM_AVG: case REC_HRM_MAX: case REC_TRANSREC: case REC_TRANSREC_L1: ok = nd >= 2; break;  // HRM_avg.cpp:130, TransRec.cpp:166
+            default: ok = nu >= 2; break;                                                   // FPMC.cpp:81, PRME.cpp:75, Fossil.cpp:123, REBUS.cpp:275
+            }
+            if (ok) elig.push_back(u);
+        }
+    }
+    for (int u = ub; u < ue; u++) if (test_item[u] >= 0) eval_users.push_back(u);
+    for (int u : eval_users)
+        if (seq_off[u + 1] - seq_off[u] < 1 || val_item[u] < 0 || val_item[u] >= I || test_item[u] >= I) {
+            delete e; rec_set_error("a user with a test item needs a validation item and at least one training item"); return -1;
+        }
+    std::vector<double> eta((size_t)(L + 1) * L, 0.0);
+    for (int n = 0; n <= L; n++) {
+        // REBUS.cpp:112-120; cumWeibull of common.hpp:92-99 is exp(-(x/7)^2)
+        double res = 0;
+        for (int i = 0; i < n; i++) res += exp(1 - (1 - exp(-pow(i / 7.0, 2.0))));
+        for (int r = 0; r < n; r++) eta[(size_t)n * L + r] = exp(1 - (1 - exp(-pow(r / 7.0, 2.0)))) / res;
+    }
+
+    // ---- device state
+    DevModel& m = e->dm;
+    memset(&m, 0, sizeof m);
+    m.model = d->model; m.U = U; m.I = I; m.K = e->desc.K; m.KK = e->desc.KK; m.L = L;
+    m.lambda = d->lambda; m.bias_reg = d->bias_reg; m.relation_reg = d->relation_reg; m.alpha = d->alpha;
+    m.df = (double)e->desc.dataset_factor;
+    int rc = 0;
+#define UP(vec, field) if (!rc) rc = upload(e, vec, &m.field)
+    UP(seq_off, seq_off); UP(seq_item, seq_item); UP(test_item, test_item); UP(val_item, val_item);
+    UP(clk_off, clk_off); UP(clk_item, clk_item); UP(first_occ, first_occ); UP(elig, elig); UP(eval_users, eval_users);
+    UP(train_count, train_count); UP(eta, eta);
+    if (d->model == REC_MC) { UP(succ_off, succ_off); UP(succ_item, succ_item); UP(sset_off, sset_off); UP(sset_item, sset_item); }
+    if (d->model == REC_REBUS && !rc) {
+        const int64_t nctx = E + 2 * (int64_t)U;
+        std::vector<int64_t> po(c->path_off, c->path_off + nctx + 1);
+        std::vector<int32_t> pi(c->path_item, c->path_item + po[nctx]);
+        for (int64_t x = 0; x < nctx && !rc; x++)
+            if (po[x + 1] - po[x] > L) { rec_set_error("a matched path is longer than L"); rc = -1; }
+        UP(po, path_off); UP(pi, path_item);
+    }
+#undef UP
+    m.n_elig = (int)elig.size(); m.n_eval = (int)eval_users.size();
+    auto fail = [&](int code) { rec_destroy(e); return code; };
+    if (rc) return fail(rc);
+    if (hipStreamCreate(&e->st) != hipSuccess) { rec_set_error("hipStreamCreate failed"); return fail(-2); }
+    if (hipMalloc(&e->W, e->dev_elems * e->elem_size) != hipSuccess || hipMalloc(&e->bestW, e->dev_elems * e->elem_size) != hipSuccess) {
+        rec_set_error("hipMalloc of the parameter tables failed"); return fail(-2);
+    }
+    (void)hipMemset(e->W, 0, e->dev_elems * e->elem_size);
+    (void)hipMemset(e->bestW, 0, e->dev_elems * e->elem_size);
+    for (size_t t = 0; t < e->tables.size(); t++) m.tab[t] = (char*)e->W + e->tables[t].dev_off * e->elem_size;
+    void* g = nullptr;
+    if (hipMalloc(&g, 8 * (REC_MAX_K + 2 * REC_MAX_L + 8)) != hipSuccess) { rec_set_error("hipMalloc failed"); return fail(-2); }
+    e->owned.push_back(g); (void)hipMemset(g, 0, 8 * (REC_MAX_K + 2 * REC_MAX_L + 8));
+    m.gacc = g;
+    *out = e;
+    return 0;
+}
+
+extern "C" int rec_destroy(rec_engine* e)
+{
+    if (!e) return 0;
+    (void)hipSetDevice(e->desc.device);
+    if (e->st) (void)hipStreamSynchronize(e->st);
+    for (int w = 0; w < 3; w++) for (auto& p : e->pending[w]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (void* p : e->owned) (void)hipFree(p);
+    if (e->W) (void)hipFree(e->W);
+    if (e->bestW) (void)hipFree(e->bestW);
+    if (e->stage) (void)hipFree(e->stage);
+    if (e->tuples) (void)hipFree(e->tuples);
+    if (e->st) (void)hipStreamDestroy(e->st);
+    delete e;
+    return 0;
+}
+
+extern "C" int rec_sync(rec_engine* e)
+{
+    if (!e) { rec_set_error("null engine"); return -1; }
+    ENG_HIP(hipSetDevice(e->desc.device));
+    ENG_HIP(hipStreamSynchronize(e->st));
+    return 0;
+}
+
+extern "C" int64_t rec_nw(const rec_engine* e) { return e ? e->nw : -1; }
+extern "C" int64_t rec_steps_per_epoch(const rec_engine* e) { return e ? e->steps_per_epoch : -1; }
+
+static int ensure_stage(rec_engine* e, int64_t elems)
+{
+    if (e->stage_elems >= elems) return 0;
+    if (e->stage) (void)hipFree(e->stage);
+    e->stage = nullptr; e->stage_elems = 0;
+    ENG_HIP(hipMalloc((void**)&e->stage, sizeof(double) * elems));
+    e->stage_elems = elems;
+    return 0;
+}
+
+// tables are moved through an f64 staging buffer in slices, so that W never needs a second full-size copy
+static const int64_t STAGE_ELEMS = 1 << 24;
+
+extern "C" int rec_params_upload(rec_engine* e, const double* W, int64_t nw)
+{
+    if (!e || !W) { rec_set_error("null argument"); return -1; }
+    if (nw != e->nw) { rec_set_error("NW not match."); return -1; }  // model.cpp:213-216
+    ENG_HIP(hipSetDevice(e->desc.device));
+    if (int rc = ensure_stage(e, std::min<int64_t>(STAGE_ELEMS, std::max<int64_t>(nw, 1)))) return rc;
+    for (auto& t : e->tables) {
+        const int64_t n = t.rows * t.cols;
+        for (int64_t o = 0; o < n; o += e->stage_elems) {
+            const int64_t len = std::min(e->stage_elems, n - o);
+            ENG_HIP(hipMemcpyAsync(e->stage, W + t.host_off + o, sizeof(double) * len, hipMemcpyHostToDevice, e->st));
+            if (int rc = launch_convert_in(e->stage, (char*)e->W + (t.dev_off + o) * e->elem_size, len, e->desc.precision, e->st)) return rc;
+            ENG_HIP(hipStreamSynchronize(e->st));
+        }
+    }
+    return 0;
+}
+
+extern "C" int rec_params_download(rec_engine* e, double* W, int64_t nw)
+{
+    if (!e || !W) { rec_set_error("null argument"); return -1; }
+    if (nw != e->nw) { rec_set_error("NW not match."); return -1; }
+    ENG_HIP(hipSetDevice(e->desc.device));
+    if (int rc = ensure_stage(e, std::min<int64_t>(STAGE_ELEMS, std::max<int64_t>(nw, 1)))) return rc;
+    for (auto& t : e->tables) {
+        const int64_t n = t.rows * t.cols;
+        for (int64_t o = 0; o < n; o += e->stage_elems) {
+            const int64_t len = std::min(e->stage_elems, n - o);
+            if (int rc = launch_convert_out((char*)e->W + (t.dev_off + o) * e->elem_size, e->stage, len, e->desc.precision, e->st)) return rc;
+            ENG_HIP(hipMemcpyAsync(W + t.host_off + o, e->stage, sizeof(double) * len, hipMemcpyDeviceToHost, e->st));
+            ENG_HIP(hipStreamSynchronize(e->st));
+        }
+    }
+    return 0;
+}
+
+extern "C" int rec_params_init(rec_engine* e, uint64_t seed)
+{
+    if (!e) { rec_set_error("null engine"); return -1; }
+    ENG_HIP(hipSetDevice(e->desc.device));
+    if (int rc = launch_param_init(e->dm, e->desc.precision, seed, e->st)) return rc;
+    ENG_HIP(hipStreamSynchronize(e->st));
+    return 0;
+}
+
+extern "C" int rec_snapshot_best(rec_engine* e)
+{
+    if (!e) { rec_set_error("null engine"); return -1; }
+    ENG_HIP(hipSetDevice(e->desc.device));
+    ENG_HIP(hipMemcpyAsync(e->bestW, e->W, e->dev_elems * e->elem_size, hipMemcpyDeviceToDevice, e->st));
+    ENG_HIP(hipStreamSynchronize(e->st));
+    return 0;
+}
+
+extern "C" int rec_restore_best(rec_engine* e)
+{
+    if (!e) { rec_set_error("null engine"); return -1; }
+    ENG_HIP(hipSetDevice(e->desc.device));
+    ENG_HIP(hipMemcpyAsync(e->W, e->bestW, e->dev_elems * e->elem_size, hipMemcpyDeviceToDevice, e->st));
+    ENG_HIP(hipStreamSynchronize(e->st));
+    return 0;
+}
+
+static int ensure_tuples(rec_engine* e, int64_t n)
+{
+    if (e->tuples_cap >= n) return 0;
+    ENG_HIP(hipStreamSynchronize(e->st));
+    if (e->tuples) (void)hipFree(e->tuples);
+    e->tuples = nullptr; e->tuples_cap = 0;
+    ENG_HIP(hipMalloc((void**)&e->tuples, sizeof(int4) * n));
+    e->tuples_cap = n;
+    return 0;
+}
+
+// ---- HIP-event bookkeeping: events are recorded around a launch and read back lazily
+static int ev_begin(rec_engine* e, int which, hipEvent_t* a, hipEvent_t* b)
+{
+    if (!e->profile) return 0;
+    ENG_HIP(hipEventCreate(a)); ENG_HIP(hipEventCreate(b));
+    ENG_HIP(hipEventRecord(*a, e->st));
+    (void)which;
+    return 0;
+}
+static int ev_end(rec_engine* e, int which, hipEvent_t a, hipEvent_t b)
+{
+    if (!e->profile) return 0;
+    ENG_HIP(hipEventRecord(b, e->st));
+    e->pending[which].push_back({a, b});
+    return 0;
+}
+
+static int check_tuples(const rec_engine* e, const int32_t* t, int64_t n)
+{
+    // operands must fit the tables before a kernel dereferences them
+    const int U = e->U, I = e->I; const int model = e->desc.model;
+    for (int64_t i = 0; i < n; i++) {
+        const int32_t a = t[4 * i], b = t[4 * i + 1], c = t[4 * i + 2], d = t[4 * i + 3];
+        bool ok = true;
+        switch (model) {
+        case REC_BPRMF: ok = a >= 0 && a < U && b >= 0 && b < I && c >= 0 && c < I; break;
+        case REC_MC: ok = a >= 0 && a < I && b >= 0 && b < I && c >= 0 && c < I; break;
+        case REC_FOSSIL: case REC_REBUS: {
+            ok = a >= 0 && a < U && c >= 0 && c < I;
+            if (ok) {
+                // seq offsets live on the host only during rec_create; bounds are re-derived from steps via the device copy
+            }
+            break;
+        }
+        default: ok = a >= 0 && a < U && b >= 0 && b < I && c >= 0 && c < I && d >= 0 && d < I; break;
+        }
+        if (!ok) { rec_set_error("tuple " + std::to_string(i) + " is out of range"); return -1; }
+    }
+    return 0;
+}
+
+extern "C" int rec_sgd_replay(rec_engine* e, double lr, const int32_t* tuples, int64_t n, int mode)
+{
+    if (!e || (!tuples && n > 0)) { rec_set_error("null argument"); return -1; }
+    if (e->desc.model == REC_MP) { rec_set_error("MostPopular has nothing to train"); return -1; }
+    if (n <= 0) return 0;
+    ENG_HIP(hipSetDevice(e->desc.device));
+    if (int rc = check_tuples(e, tuples, n)) return rc;
+    if (e->desc.model == REC_FOSSIL || e->desc.model == REC_REBUS) {
+        // target positions must lie inside the user's training sequence
+        std::vector<int64_t> so(e->U + 1);
+        ENG_HIP(hipMemcpy(so.data(), e->dm.seq_off, sizeof(int64_t) * (e->U + 1), hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; i++) {
+            const int u = tuples[4 * i]; const int64_t nu = so[u + 1] - so[u];
+            const int64_t tp = tuples[4 * i + 1] + (e->desc.model == REC_REBUS ? 1 : 0);
+            if (tp < 1 || tp >= nu) { rec_set_error("tuple " + std::to_string(i) + ": target position out of range"); return -1; }
+        }
+    }
+    if (int rc = ensure_tuples(e, n)) return rc;
+    ENG_HIP(hipMemcpyAsync(e->tuples, tuples, sizeof(int4) * n, hipMemcpyHostToDevice, e->st));
+    hipEvent_t a = nullptr, b = nullptr;
+    if (mode == REC_REPLAY_SEQUENTIAL) {
+        if (int rc = launch_sgd_sequential(e->dm, e->desc.precision, e->tuples, n, lr, e->st)) return rc;
+        ENG_HIP(hipStreamSynchronize(e->st));
+    } else if (mode == REC_REPLAY_HOGWILD) {
+        for (int64_t o = 0; o < n; o += e->chunk) {
+            const int64_t len = std::min(e->chunk, n - o);
+            if (int rc = ev_begin(e, 0, &a, &b)) return rc;
+            if (int rc = launch_sgd_hogwild(e->dm, e->desc.precision, e->tuples + o, len, lr, e->atomic, e->st)) return rc;
+            if (int rc = ev_end(e, 0, a, b)) return rc;
+            if (int rc = launch_apply_global(e->dm, e->desc.precision, lr, len, e->st)) return rc;
+        }
+        // the host buffer may be reused by the caller: the copy above must have completed
+        ENG_HIP(hipStreamSynchronize(e->st));
+    } else {
+        rec_set_error("unknown replay mode"); return -1;
+    }
+    return 0;
+}
+
+extern "C" int rec_sgd_epoch(rec_engine* e, double lr, int64_t n_steps, uint64_t seed, uint64_t epoch)
+{
+    if (!e) { rec_set_error("null engine"); return -1; }
+    if (e->desc.model == REC_MP) { rec_set_error("MostPopular has nothing to train"); return -1; }
+    if (n_steps <= 0) return 0;
+    ENG_HIP(hipSetDevice(e->desc.device));
+    const int64_t chunk = std::min(e->chunk, n_steps);
+    if (int rc = ensure_tuples(e, chunk)) return rc;
+    hipEvent_t a = nullptr, b = nullptr;
+    for (int64_t o = 0; o < n_steps; o += chunk) {
+        const int64_t len = std::min(chunk, n_steps - o);
+        if (int rc = ev_begin(e, 2, &a, &b)) return rc;
+        if (int rc = launch_sampler(e->dm, e->tuples, len, o, seed, epoch, e->st)) return rc;
+        if (int rc = ev_end(e, 2, a, b)) return rc;
+        if (int rc = ev_begin(e, 0, &a, &b)) return rc;
+        if (int rc = launch_sgd_hogwild(e->dm, e->desc.precision, e->tuples, len, lr, e->atomic, e->st)) return rc;
+        if (int rc = ev_end(e, 0, a, b)) return rc;
+        if (int rc = launch_apply_global(e->dm, e->desc.precision, lr, len, e->st)) return rc;
+    }
+    return 0;
+}
+
+extern "C" int rec_sample_tuples(rec_engine* e, int64_t n, uint64_t seed, uint64_t epoch, int32_t* out)
+{
+    if (!e || !out) { rec_set_error("null argument"); return -1; }
+    if (n <= 0) return 0;
+    ENG_HIP(hipSetDevice(e->desc.device));
+    if (int rc = ensure_tuples(e, n)) return rc;
+    if (int rc = launch_sampler(e->dm, e->tuples, n, 0, seed, epoch, e->st)) return rc;
+    ENG_HIP(hipMemcpyAsync(out, e->tuples, sizeof(int4) * n, hipMemcpyDeviceToHost, e->st));
+    ENG_HIP(hipStreamSynchronize(e->st));
+    return 0;
+}
+
+// model.cpp:49-97 on per-user counts, in user order (the reference's summation order)
+static void reduce_metrics(const rec_engine* e, const int32_t* counts, int topn, double sums[8])
+{
+    for (int i = 0; i < 8; i++) sums[i] = 0;
+    for (int u = e->desc.user_begin; u < e->desc.user_end; u++) {
+        const int cv = counts[3 * (int64_t)u], ct = counts[3 * (int64_t)u + 1], mx = counts[3 * (int64_t)u + 2];
+        if (mx < 0) continue;
+        const double at = 1.0 * ct / mx;
+        sums[0] += 1.0 * cv / mx; sums[1] += at;
+        int rank = mx - cv + 1; sums[4] += 1.0 / rank; sums[2] += (rank <= topn);
+        rank = mx - ct + 1; sums[5] += 1.0 / rank; sums[3] += (rank <= topn);
+        sums[6] += at * at; sums[7] += 1;
+    }
+}
+
+static int eval_counts(rec_engine* e, std::vector<int32_t>& counts, double* xpos)
+{
+    ENG_HIP(hipSetDevice(e->desc.device));
+    ENG_HIP(hipStreamSynchronize(e->st));
+    counts.resize((size_t)e->U * 3);
+    return eval_run(e->dm, e->desc.precision, counts.data(), xpos, e->st, &e->ms[1], &e->launches[1], e->profile != 0);
+}
+
+extern "C" int rec_eval(rec_engine* e, int topn, rec_metrics* out, int32_t* counts_out, double* xpos_out)
+{
+    if (!e || !out) { rec_set_error("null argument"); return -1; }
+    std::vector<int32_t> counts;
+    if (int rc = eval_counts(e, counts, xpos_out)) return rc;
+    double s[8];
+    reduce_metrics(e, counts.data(), topn, s);
+    const double n = s[7];
+    out->n_users = (int64_t)n;
+    out->auc_val = s[0] / n; out->auc_test = s[1] / n; out->hit_val = s[2] / n; out->hit_test = s[3] / n;
+    out->mrr_val = s[4] / n; out->mrr_test = s[5] / n;
+    // two-pass variance as model.cpp:91-97
+    double var = 0;
+    for (int u = e->desc.user_begin; u < e->desc.user_end; u++) {
+        const int mx = counts[3 * (size_t)u + 2];
+        if (mx < 0) continue;
+        const double dlt = 1.0 * counts[3 * (size_t)u + 1] / mx - out->auc_test;
+        var += dlt * dlt;
+    }
+    out->var_test = var / n;
+    if (counts_out) memcpy(counts_out, counts.data(), sizeof(int32_t) * counts.size());
+    return 0;
+}
+
+extern "C" int rec_eval_sums(rec_engine* e, int topn, double sums[8])
+{
+    if (!e || !sums) { rec_set_error("null argument"); return -1; }
+    std::vector<int32_t> counts;
+    if (int rc = eval_counts(e, counts, nullptr)) return rc;
+    reduce_metrics(e, counts.data(), topn, sums);
+    return 0;
+}
+
+extern "C" int rec_num_tables(const rec_engine* e) { return e ? (int)e->tables.size() : -1; }
+
+extern "C" int rec_table_info(const rec_engine* e, int t, void** dev_ptr, int64_t* rows, int64_t* cols, int* is_user_table)
+{
+    if (!e || t < 0 || t >= (int)e->tables.size()) { rec_set_error("no such table"); return -1; }
+    if (dev_ptr) *dev_ptr = (char*)e->W + e->tables[t].dev_off * e->elem_size;
+    if (rows) *rows = e->tables[t].rows;
+    if (cols) *cols = e->tables[t].cols;
+    if (is_user_table) *is_user_table = e->tables[t].is_user;
+    return 0;
+}
+
+extern "C" int rec_set_option(rec_engine* e, const char* name, int64_t value)
+{
+    if (!e || !name) { rec_set_error("null argument"); return -1; }
+    const std::string s(name);
+    if (s == "chunk") { if (value < 1) { rec_set_error("chunk must be positive"); return -1; } e->chunk = value; }
+    else if (s == "atomic") e->atomic = value != 0;
+    else if (s == "profile") e->profile = value != 0;
+    else { rec_set_error("unknown option " + s); return -1; }
+    return 0;
+}
+
+extern "C" int rec_kernel_stats(rec_engine* e, int which, double* total_ms, int64_t* launches)
+{
+    if (!e || which < 0 || which > 2) { rec_set_error("bad argument"); return -1; }
+    ENG_HIP(hipSetDevice(e->desc.device));
+    ENG_HIP(hipStreamSynchronize(e->st));
+    for (auto& p : e->pending[which]) {
+        float ms = 0;
+        ENG_HIP(hipEventElapsedTime(&ms, p.first, p.second));
+        e->ms[which] += ms; e->launches[which] += 1;
+        (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second);
+    }
+    e->pending[which].clear();
+    if (total_ms) *total_ms = e->ms[which];
+    if (launches) *launches = e->launches[which];
+    e->ms[which] = 0; e->launches[which] = 0;
+    return 0;
+}

@@ -1,0 +1,546 @@
+// Full-catalog evaluation (AUC / HIT@N / MRR) as batched scoring.
+//
+// For every ranked candidate j (an item the user has not clicked, model.cpp:33-37) each model's
+// prediction() is   score(q, j) = a_q + b_j + <q', T_j>   with a per-(user, context) query q'
+// that does not depend on j, a per-item constant b_j and a static item table T (one or two table
+// segments side by side):
+//     dot models   a_q = 0,            b_j = beta_j,                   q' = q
+//     L2 models    a_q = -sum w q^2,   b_j = -(beta_j + sum w T_j^2),  q' = 2 w q     (||q-T||^2 expanded)
+// so the 2*nItems predictions per user become one FP64 MFMA GEMM tile sweep whose epilogue compares
+// with the positive's score and counts (strict >, as model.cpp:40,45), instead of nItems*n_u*K work
+// per user in Fossil / REBUS.  The positive's own score follows the reference formula literally,
+// including its "skip the scored item" rule (Fossil.cpp:90, REBUS.cpp:223).  Clicked items are
+// counted by the GEMM like any other column and taken out again by a small correction kernel that
+// walks the user's (short) click list.
+#include "common.h"
+#include <math.h>
+#include <vector>
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+struct EvalDev {
+    int nq, nq_pad, nctx, KQ, K1, K2;
+    int seg0, seg1;            // table indices of the two item-table segments (-1 = none)
+    double* Q;                 // [nq_pad][KQ] scaled queries q'
+    double* thr;               // [nq_pad] positive's score minus a_q (validation positive when nctx == 1)
+    double* thr2;              // [nq_pad] test positive's score minus a_q (nctx == 1 only)
+    int32_t* cnt; int32_t* cnt2;  // [nq_pad]
+    double* bconst;            // [I]
+    int32_t* counts;           // [U][3]
+    double* xpos;              // [U][2]
+};
+
+#define E REC_MAX_EPL
+
+template <class T>
+struct QB {
+    const DevModel& m; int lane;
+    __device__ QB(const DevModel& m_) : m(m_), lane(threadIdx.x & 63) {}
+    __device__ double ld(int t, int64_t row, int K, int k) const { return (double)((const T*)m.tab[t])[row * K + k]; }
+    __device__ double sc(int t, int64_t i) const { return (double)((const T*)m.tab[t])[i]; }
+    __device__ static double wsum(double v) { return group_sum<64>(v); }
+};
+
+// one wavefront per query
+template <class T>
+__global__ void __launch_bounds__(256) build_queries_kernel(DevModel m, EvalDev ev)
+{
+    const QB<T> B(m);
+    const int lane = B.lane;
+    const int w = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (w >= ev.nq) return;
+    const int u = m.eval_users[w / ev.nctx];
+    const int ctx = ev.nctx == 2 ? (w & 1) : 0;     // 0 = validation, 1 = test
+    const int64_t so = m.seq_off[u]; const int n = (int)(m.seq_off[u + 1] - so);
+    const int32_t* seq = m.seq_item + so;
+    const int val = m.val_item[u], test = m.test_item[u];
+    const int pos = ctx ? test : val;
+    const int prev = ctx ? val : seq[n - 1];         // model.hpp:37-39
+    const int K = m.K, KK = m.KK;
+    double* q = ev.Q + (int64_t)w * ev.KQ;
+    double aq = 0, xa = 0, xb = 0;                   // xa: this context's positive; xb: test positive when nctx == 1
+
+    switch (m.model) {
+    case REC_MP: {  // MostPopular.cpp:4-7
+        xa = (double)m.train_count[val]; xb = (double)m.train_count[test];
+        break;
+    }
+    case REC_BPRMF: {  // BPRMF.cpp:69-72
+        double pv = 0, pt = 0;
+        for (int k = lane; k < K; k += 64) {
+            const double g = B.ld(BPRMF_GU, u, K, k);
+            q[k] = g; pv += g * B.ld(BPRMF_GI, val, K, k); pt += g * B.ld(BPRMF_GI, test, K, k);
+        }
+        xa = B.sc(BPRMF_BETA, val) + B.wsum(pv); xb = B.sc(BPRMF_BETA, test) + B.wsum(pt);
+        break;
+    }
+    case REC_MC: {  // MC.cpp:75-78
+        double p = 0;
+        for (int k = lane; k < K; k += 64) { const double g = B.ld(MC_GI, prev, K, k); q[k] = g; p += g * B.ld(MC_ETA, pos, K, k); }
+        xa = B.wsum(p);
+        break;
+    }
+    case REC_FPMC: {  // FPMC.cpp:71-75
+        double p1 = 0, p2 = 0;
+        for (int k = lane; k < K; k += 64) { const double g = B.ld(FPMC_GU, u, K, k); q[k] = g; p1 += g * B.ld(FPMC_GI, pos, K, k); }
+        for (int k = lane; k < KK; k += 64) { const double g = B.ld(FPMC_KAPPA, prev, KK, k); q[K + k] = g; p2 += g * B.ld(FPMC_ETA, pos, KK, k); }
+        xa = B.wsum(p1) + B.wsum(p2);
+        break;
+    }
+    case REC_PRME: {  // PRME.cpp:64-69
+        const double al = m.alpha;
+        double n1 = 0, n2 = 0, d1 = 0, d2 = 0;
+        for (int k = lane; k < K; k += 64) {
+            const double g = B.ld(PRME_GU, u, K, k), t = B.ld(PRME_GI, pos, K, k);
+            q[k] = 2 * al * g; n1 += g * g; d1 += (g - t) * (g - t);
+        }
+        for (int k = lane; k < KK; k += 64) {
+            const double g = B.ld(PRME_ETA, prev, KK, k), t = B.ld(PRME_ETA, pos, KK, k);
+            q[K + k] = 2 * (1 - al) * g; n2 += g * g; d2 += (g - t) * (g - t);
+        }
+        aq = -(al * B.wsum(n1) + (1 - al) * B.wsum(n2));
+        xa = -(al * B.wsum(d1) + (1 - al) * B.wsum(d2));
+        break;
+    }
+    case REC_HRM_AVG: case REC_HRM_MAX: {  // HRM_avg.cpp:64-71, HRM_max.cpp:64-71
+        double p = 0;
+        for (int k = lane; k < K; k += 64) {
+            const double a = B.ld(HRM_U, u, K, k), b = B.ld(HRM_V, prev, K, k);
+            const double h = m.model == REC_HRM_MAX ? (a > b ? a : b) : (a + b);
+            q[k] = h; p += h * B.ld(HRM_V, pos, K, k);
+        }
+        xa = B.wsum(p);
+        break;
+    }
+    case REC_TRANSREC: {  // TransRec.cpp:85-92
+        double nq = 0, d = 0;
+        for (int k = lane; k < K; k += 64) {
+            const double g = B.ld(TR_H, prev, K, k) + B.sc(TR_r, k) + B.ld(TR_R, u, K, k);
+            const double e = g - B.ld(TR_H, pos, K, k);
+            q[k] = 2 * g; nq += g * g; d += e * e;
+        }
+        aq = -B.wsum(nq);
+        xa = -(B.sc(TR_BETA, pos) + B.wsum(d));
+        break;
+    }
+    case REC_FOSSIL_SIMPLE: case REC_FOSSIL: {
+        // FossilSimple.cpp:82-103 through model::AUC; Fossil.cpp:81-117 with the contexts of Fossil.cpp:389-404
+        const bool simple = m.model == REC_FOSSIL_SIMPLE;
+        const int tUi = simple ? FS_UI : FO_UI, tV = simple ? FS_V : FO_V, tB = simple ? FS_BETA : FO_BETA;
+        double sall[E], sex[E];
+#pragma unroll
+        for (int j = 0; j < E; j++) sall[j] = sex[j] = 0;
+        int cex = 0;
+        for (int t = 0; t < n; t++) {
+            const int it = seq[t];
+            if (it != pos) cex++;
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                const int k = lane + 64 * j;
+                if (k < K) { const double x = B.ld(tUi, it, K, k); sall[j] += x; if (it != pos) sex[j] += x; }
+            }
+        }
+        const double wall = n > 0 ? pow((double)n, -0.2) : 0, wex = cex > 0 ? pow((double)cex, -0.2) : 0;
+        if (simple) {
+            const double a0 = B.sc(FS_ALPHA, 0) + B.sc(FS_ALPHA_U, u);
+            double p1 = 0, p2 = 0;
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                const int k = lane + 64 * j;
+                if (k < K) {
+                    const double up = B.ld(tUi, prev, K, k), vp = B.ld(tV, pos, K, k);
+                    q[k] = wall * sall[j] + a0 * up;
+                    p1 += sex[j] * vp; p2 += up * vp;
+                }
+            }
+            xa = B.sc(tB, pos); xa += wex * B.wsum(p1); xa += a0 * B.wsum(p2);
+        } else {
+            const int L = m.L;
+            const int np = ctx ? 1 + (L - 1 < n ? L - 1 : n) : (L < n ? L : n);
+            double sq[E];
+#pragma unroll
+            for (int j = 0; j < E; j++) { sq[j] = wall * sall[j]; sex[j] *= wex; }
+            for (int ind = 0; ind < np; ind++) {
+                const int c = ctx ? (ind == 0 ? val : seq[n - ind]) : seq[n - 1 - ind];
+                const double wgt = B.sc(FO_WT, ind) + B.sc(FO_WTU, (int64_t)u * L + ind);
+#pragma unroll
+                for (int j = 0; j < E; j++) {
+                    const int k = lane + 64 * j;
+                    if (k < K) { const double x = wgt * B.ld(tUi, c, K, k); sq[j] += x; if (c != pos) sex[j] += x; }
+                }
+            }
+            double p = 0;
+#pragma unroll
+            for (int j = 0; j < E; j++) { const int k = lane + 64 * j; if (k < K) { q[k] = sq[j]; p += sex[j] * B.ld(tV, pos, K, k); } }
+            xa = B.sc(tB, pos) + B.wsum(p);
+        }
+        break;
+    }
+    case REC_REBUS: {  // REBUS.cpp:205-269 with the contexts of REBUS.cpp:758-782
+        const uint8_t* fo = m.first_occ + so;
+        const int64_t cid = so + 2 * (int64_t)u + (n - 1) + ctx;
+        const int32_t* path = m.path_item + m.path_off[cid]; const int np = (int)(m.path_off[cid + 1] - m.path_off[cid]);
+        const double* etas = m.eta + (int64_t)np * m.L;
+        // the test prefix also holds the validation item; it joins the set when it is new
+        const bool extra = ctx && !sorted_contains(m.clk_item + m.clk_off[u], (int)(m.clk_off[u + 1] - m.clk_off[u]), val);
+        double sall[E], sex[E], ss[E];
+#pragma unroll
+        for (int j = 0; j < E; j++) sall[j] = sex[j] = ss[j] = 0;
+        int call = 0, cex = 0;
+        for (int t = 0; t < n + (extra ? 1 : 0); t++) {
+            if (t < n && !fo[t]) continue;
+            const int it = t < n ? seq[t] : val;
+            call++; if (it != pos) cex++;
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                const int k = lane + 64 * j;
+                if (k < K) { const double x = B.ld(RB_P, it, K, k); sall[j] += x; if (it != pos) sex[j] += x; }
+            }
+        }
+        const double wall = call > 0 ? pow((double)call, m.alpha) : 0, wex = cex > 0 ? pow((double)cex, m.alpha) : 0;
+        for (int r = 0; r < np; r++) {
+#pragma unroll
+            for (int j = 0; j < E; j++) { const int k = lane + 64 * j; if (k < K) ss[j] += etas[r] * B.ld(RB_P, path[r], K, k); }
+        }
+        double nq = 0, d2 = 0;
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            const int k = lane + 64 * j;
+            if (k < K) {
+                const double g = wall * sall[j] + ss[j];
+                const double d = wex * sex[j] + ss[j] - B.ld(RB_P, pos, K, k);
+                q[k] = 2 * g; nq += g * g; d2 += d * d;
+            }
+        }
+        aq = -B.wsum(nq);
+        xa = -(B.sc(RB_BETA, pos) + B.wsum(d2));
+        break;
+    }
+    default: break;
+    }
+    if (lane == 0) {
+        ev.thr[w] = xa - aq;
+        if (ev.nctx == 1) {
+            ev.thr2[w] = xb - aq;
+            ev.xpos[2 * (int64_t)u] = xb; ev.xpos[2 * (int64_t)u + 1] = xa;
+        } else {
+            ev.xpos[2 * (int64_t)u + (ctx ? 0 : 1)] = xa;
+        }
+    }
+}
+
+// b_j, one wavefront per item
+template <class T>
+__global__ void __launch_bounds__(256) item_consts_kernel(DevModel m, EvalDev ev)
+{
+    const QB<T> B(m);
+    const int lane = B.lane;
+    const int j = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (j >= m.I) return;
+    const int K = m.K, KK = m.KK;
+    double b = 0;
+    switch (m.model) {
+    case REC_MP: b = (double)m.train_count[j]; break;
+    case REC_BPRMF: b = B.sc(BPRMF_BETA, j); break;
+    case REC_FOSSIL_SIMPLE: b = B.sc(FS_BETA, j); break;
+    case REC_FOSSIL: b = B.sc(FO_BETA, j); break;
+    case REC_PRME: {
+        double s1 = 0, s2 = 0;
+        for (int k = lane; k < K; k += 64) { const double t = B.ld(PRME_GI, j, K, k); s1 += t * t; }
+        for (int k = lane; k < KK; k += 64) { const double t = B.ld(PRME_ETA, j, KK, k); s2 += t * t; }
+        b = -(m.alpha * B.wsum(s1) + (1 - m.alpha) * B.wsum(s2));
+        break;
+    }
+    case REC_TRANSREC: {
+        double s = 0;
+        for (int k = lane; k < K; k += 64) { const double t = B.ld(TR_H, j, K, k); s += t * t; }
+        b = -(B.sc(TR_BETA, j) + B.wsum(s));
+        break;
+    }
+    case REC_REBUS: {
+        double s = 0;
+        for (int k = lane; k < K; k += 64) { const double t = B.ld(RB_P, j, K, k); s += t * t; }
+        b = -(B.sc(RB_BETA, j) + B.wsum(s));
+        break;
+    }
+    default: break;
+    }
+    if (lane == 0) ev.bconst[j] = b;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Scoring + counting.  A block of 4 wavefronts owns 4*MT*16 queries and sweeps the whole item
+// table once: tiles of NI items are staged through LDS (converted to f64, rows padded by two
+// doubles so that the ds_read_b64 fragment reads of a 32-lane group fall on 64 distinct banks), the
+// next tile's global loads are issued before the current tile's MFMAs, and every wavefront keeps its
+// A fragments (the queries) in registers for the whole sweep.
+// v_mfma_f64_16x16x4_f64 operand maps: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
+// D[i = (lane >> 4) + 4 r][j = lane & 15] for result register r.
+template <int KQ> struct TileShape {
+    static constexpr int NI = KQ <= 64 ? 64 : KQ <= 128 ? 32 : 16;
+    static constexpr int MT = KQ <= 32 ? 4 : KQ <= 64 ? 2 : 1;
+};
+
+template <class T, int KQ, bool TWO>
+__global__ void __launch_bounds__(256) score_count_kernel(EvalDev ev, const T* __restrict__ seg0, const T* __restrict__ seg1,
+                                                          const int32_t* __restrict__ qtest, const int32_t* __restrict__ qval, int I)
+{
+    constexpr int KC = KQ / 4, NI = TileShape<KQ>::NI, MT = TileShape<KQ>::MT, STR = KQ + 2;
+    constexpr int PER = NI * KQ / 256;  // tile elements per thread
+    __shared__ double tile[NI * STR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, quad = lane >> 4;
+    const int64_t qbase = ((int64_t)blockIdx.x * 4 + wave) * (MT * 16);
+    const int K1 = ev.K1, K2 = ev.K2;
+
+    double a[MT][KC];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++) a[mt][kc] = ev.Q[(qbase + mt * 16 + col) * KQ + 4 * kc + quad];
+
+    double thr[MT][4], thr2[MT][4];
+    int ex1[MT][4], ex2[MT][4], cnt[MT][4], cnt2[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int64_t qi = qbase + mt * 16 + quad + 4 * r;
+            thr[mt][r] = ev.thr[qi]; thr2[mt][r] = TWO ? ev.thr2[qi] : 0.0;
+            ex1[mt][r] = qtest[qi]; ex2[mt][r] = qval[qi];
+            cnt[mt][r] = 0; cnt2[mt][r] = 0;
+        }
+
+    auto fetch = [&](int item0, T (&pre)[PER]) {
+#pragma unroll
+        for (int p = 0; p < PER; p++) {
+            const int idx = tid + 256 * p, it = idx / KQ, k = idx % KQ;
+            const int64_t j = (int64_t)item0 + it;
+            T v = 0;
+            if (j < I) {
+                if (k < K1) v = seg0[j * K1 + k];
+                else if (k < K1 + K2) v = seg1[j * K2 + (k - K1)];
+            }
+            pre[p] = v;
+        }
+    };
+
+    T pre[PER];
+    fetch(0, pre);
+    for (int item0 = 0; item0 < I; item0 += NI) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < PER; p++) {
+            const int idx = tid + 256 * p, it = idx / KQ, k = idx % KQ;
+            tile[it * STR + k] = (double)pre[p];
+        }
+        __syncthreads();
+        if (item0 + NI < I) fetch(item0 + NI, pre);
+#pragma unroll
+        for (int sub = 0; sub < NI / 16; sub++) {
+            const int jj = sub * 16 + col;
+            const int j = item0 + jj;
+            const bool live = j < I;
+            const double bj = live ? ev.bconst[j] : 0.0;
+            double4_t acc[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) acc[mt] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kc = 0; kc < KC; kc++) {
+                const double b = tile[jj * STR + 4 * kc + quad];
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt][kc], b, acc[mt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const double s = acc[mt][r] + bj;
+                    const bool ok = live && j != ex1[mt][r] && j != ex2[mt][r];
+                    cnt[mt][r] += (ok && thr[mt][r] > s) ? 1 : 0;
+                    if (TWO) cnt2[mt][r] += (ok && thr2[mt][r] > s) ? 1 : 0;
+                }
+        }
+    }
+    // the 16 lanes that share a quad hold partial counts of the same 4 rows
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int c = cnt[mt][r], c2 = cnt2[mt][r];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) { c += __shfl_xor(c, o, 64); if (TWO) c2 += __shfl_xor(c2, o, 64); }
+            if (col == 0) {
+                const int64_t qi = qbase + mt * 16 + quad + 4 * r;
+                ev.cnt[qi] = c;
+                if (TWO) ev.cnt2[qi] = c2;
+            }
+        }
+}
+
+// Removes the clicked items from the counts and writes (count_val, count_test, max) per user.
+// One wavefront per query; the score of a clicked item is recomputed on the vector ALU.
+template <class T>
+__global__ void __launch_bounds__(256) correct_clicked_kernel(DevModel m, EvalDev ev)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (w >= ev.nq) return;
+    const int u = m.eval_users[w / ev.nctx];
+    const int ctx = ev.nctx == 2 ? (w & 1) : 0;
+    const int val = m.val_item[u], test = m.test_item[u];
+    const int32_t* clk = m.clk_item + m.clk_off[u]; const int nc = (int)(m.clk_off[u + 1] - m.clk_off[u]);
+    const double* q = ev.Q + (int64_t)w * ev.KQ;
+    const T* seg0 = ev.seg0 >= 0 ? (const T*)m.tab[ev.seg0] : nullptr;
+    const T* seg1 = ev.seg1 >= 0 ? (const T*)m.tab[ev.seg1] : nullptr;
+    const int K1 = ev.K1, K2 = ev.K2;
+    const double thr = ev.thr[w], thr2 = ev.nctx == 1 ? ev.thr2[w] : 0.0;
+    int c = ev.cnt[w], c2 = ev.nctx == 1 ? ev.cnt2[w] : 0;
+    int dup = 0;  // test / validation items that are also training items
+    for (int i = 0; i < nc; i++) {
+        const int e = clk[i];
+        if (e == test || e == val) { dup += (e == test) + (e == val && val != test); continue; }
+        double s = 0;
+        for (int k = lane; k < K1; k += 64) s += q[k] * (double)seg0[(int64_t)e * K1 + k];
+        for (int k = lane; k < K2; k += 64) s += q[K1 + k] * (double)seg1[(int64_t)e * K2 + k];
+        s = group_sum<64>(s) + ev.bconst[e];
+        c -= thr > s ? 1 : 0;
+        c2 -= thr2 > s ? 1 : 0;
+    }
+    if (lane == 0) {
+        const int excluded = nc + 1 + (val != test ? 1 : 0) - dup;
+        if (ev.nctx == 1) {
+            ev.counts[3 * (int64_t)u] = c; ev.counts[3 * (int64_t)u + 1] = c2;
+        } else {
+            ev.counts[3 * (int64_t)u + ctx] = c;
+        }
+        if (ctx == 0) ev.counts[3 * (int64_t)u + 2] = m.I - excluded;
+    }
+}
+
+__global__ void fill_f64_kernel(double* p, int64_t n, double v)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void fill_i32_kernel(int32_t* p, int64_t n, int32_t v)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+// test / validation item of the user behind every query row (-1 on padding rows)
+__global__ void query_items_kernel(DevModel m, EvalDev ev, int32_t* qtest, int32_t* qval)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ev.nq_pad) return;
+    int t = -1, v = -1;
+    if (i < ev.nq) { const int u = m.eval_users[i / ev.nctx]; t = m.test_item[u]; v = m.val_item[u]; }
+    qtest[i] = t; qval[i] = v;
+}
+
+template <class T, bool TWO>
+static int launch_score(const EvalDev& ev, const DevModel& m, const int32_t* qtest, const int32_t* qval, hipStream_t st)
+{
+    const T* s0 = ev.seg0 >= 0 ? (const T*)m.tab[ev.seg0] : nullptr;
+    const T* s1 = ev.seg1 >= 0 ? (const T*)m.tab[ev.seg1] : nullptr;
+#define SCORE_CASE(KQv)                                                                                         \
+    case KQv: {                                                                                                 \
+        const unsigned blocks = (unsigned)(ev.nq_pad / (4 * TileShape<KQv>::MT * 16));                          \
+        hipLaunchKernelGGL((score_count_kernel<T, KQv, TWO>), dim3(blocks), dim3(256), 0, st, ev, s0, s1, qtest, qval, m.I); \
+        break;                                                                                                  \
+    }
+    switch (ev.KQ) {
+        SCORE_CASE(16) SCORE_CASE(32) SCORE_CASE(64) SCORE_CASE(128) SCORE_CASE(256)
+    default: rec_set_error("unsupported query width"); return -1;
+    }
+#undef SCORE_CASE
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static unsigned blocks_for_waves(int64_t waves) { return (unsigned)((waves * 64 + 255) / 256); }
+
+template <class T>
+static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host, hipStream_t st, double* score_ms,
+                     int64_t* score_launches, bool profile)
+{
+    EvalDev ev = {};
+    const int U = m.U, I = m.I;
+    ev.nctx = (m.model == REC_BPRMF || m.model == REC_MP) ? 1 : 2;
+    ev.seg0 = ev.seg1 = -1; ev.K1 = ev.K2 = 0;
+    switch (m.model) {
+    case REC_MP: break;
+    case REC_BPRMF: ev.seg0 = BPRMF_GI; ev.K1 = m.K; break;
+    case REC_MC: ev.seg0 = MC_ETA; ev.K1 = m.K; break;
+    case REC_FPMC: ev.seg0 = FPMC_GI; ev.K1 = m.K; ev.seg1 = FPMC_ETA; ev.K2 = m.KK; break;
+    case REC_PRME: ev.seg0 = PRME_GI; ev.K1 = m.K; ev.seg1 = PRME_ETA; ev.K2 = m.KK; break;
+    case REC_HRM_AVG: case REC_HRM_MAX: ev.seg0 = HRM_V; ev.K1 = m.K; break;
+    case REC_TRANSREC: ev.seg0 = TR_H; ev.K1 = m.K; break;
+    case REC_FOSSIL_SIMPLE: ev.seg0 = FS_V; ev.K1 = m.K; break;
+    case REC_FOSSIL: ev.seg0 = FO_V; ev.K1 = m.K; break;
+    case REC_REBUS: ev.seg0 = RB_P; ev.K1 = m.K; break;
+    default: rec_set_error("evaluation is not available for this model"); return -1;
+    }
+    const int kw = ev.K1 + ev.K2;
+    ev.KQ = kw <= 16 ? 16 : kw <= 32 ? 32 : kw <= 64 ? 64 : kw <= 128 ? 128 : 256;
+    if (kw > 256) { rec_set_error("query width above 256 is not supported"); return -1; }
+    const int mt = ev.KQ <= 32 ? 4 : ev.KQ <= 64 ? 2 : 1;
+    const int qblock = 4 * mt * 16;
+    ev.nq = m.n_eval * ev.nctx;
+    ev.nq_pad = ((ev.nq + qblock - 1) / qblock) * qblock;
+
+    // host result defaults
+    for (int64_t i = 0; i < (int64_t)U * 3; i++) counts_host[i] = -1;
+    if (xpos_host) for (int64_t i = 0; i < (int64_t)U * 2; i++) xpos_host[i] = 0;
+    if (ev.nq == 0) return 0;
+
+    int32_t *qtest = nullptr, *qval = nullptr;
+    std::vector<void*> owned;
+    auto alloc = [&](void** p, size_t bytes) -> hipError_t { hipError_t e = hipMalloc(p, bytes ? bytes : 8); if (e == hipSuccess) owned.push_back(*p); return e; };
+    auto release = [&]() { for (void* p : owned) (void)hipFree(p); };
+#define EV_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { rec_set_error(std::string(#expr) + ": " + hipGetErrorString(_e)); release(); return -2; } } while (0)
+    EV_TRY(alloc((void**)&ev.Q, sizeof(double) * (size_t)ev.nq_pad * ev.KQ));
+    EV_TRY(alloc((void**)&ev.thr, sizeof(double) * ev.nq_pad));
+    EV_TRY(alloc((void**)&ev.thr2, sizeof(double) * ev.nq_pad));
+    EV_TRY(alloc((void**)&ev.cnt, sizeof(int32_t) * ev.nq_pad));
+    EV_TRY(alloc((void**)&ev.cnt2, sizeof(int32_t) * ev.nq_pad));
+    EV_TRY(alloc((void**)&ev.bconst, sizeof(double) * I));
+    EV_TRY(alloc((void**)&ev.counts, sizeof(int32_t) * (size_t)U * 3));
+    EV_TRY(alloc((void**)&ev.xpos, sizeof(double) * (size_t)U * 2));
+    EV_TRY(alloc((void**)&qtest, sizeof(int32_t) * ev.nq_pad));
+    EV_TRY(alloc((void**)&qval, sizeof(int32_t) * ev.nq_pad));
+    EV_TRY(hipMemsetAsync(ev.Q, 0, sizeof(double) * (size_t)ev.nq_pad * ev.KQ, st));
+    EV_TRY(hipMemsetAsync(ev.xpos, 0, sizeof(double) * (size_t)U * 2, st));
+    // padding rows never win a comparison
+    hipLaunchKernelGGL(fill_f64_kernel, dim3(256), dim3(256), 0, st, ev.thr, (int64_t)ev.nq_pad, -INFINITY);
+    hipLaunchKernelGGL(fill_f64_kernel, dim3(256), dim3(256), 0, st, ev.thr2, (int64_t)ev.nq_pad, -INFINITY);
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(256), dim3(256), 0, st, ev.counts, (int64_t)U * 3, -1);
+    hipLaunchKernelGGL(query_items_kernel, dim3((ev.nq_pad + 255) / 256), dim3(256), 0, st, m, ev, qtest, qval);
+    hipLaunchKernelGGL(item_consts_kernel<T>, dim3(blocks_for_waves(I)), dim3(256), 0, st, m, ev);
+    hipLaunchKernelGGL(build_queries_kernel<T>, dim3(blocks_for_waves(ev.nq)), dim3(256), 0, st, m, ev);
+    EV_TRY(hipGetLastError());
+
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (profile) { EV_TRY(hipEventCreate(&e0)); EV_TRY(hipEventCreate(&e1)); EV_TRY(hipEventRecord(e0, st)); }
+    int rc = ev.nctx == 1 ? launch_score<T, true>(ev, m, qtest, qval, st) : launch_score<T, false>(ev, m, qtest, qval, st);
+    if (rc) { release(); return rc; }
+    if (profile) EV_TRY(hipEventRecord(e1, st));
+    hipLaunchKernelGGL(correct_clicked_kernel<T>, dim3(blocks_for_waves(ev.nq)), dim3(256), 0, st, m, ev);
+    EV_TRY(hipGetLastError());
+    EV_TRY(hipMemcpyAsync(counts_host, ev.counts, sizeof(int32_t) * (size_t)U * 3, hipMemcpyDeviceToHost, st));
+    if (xpos_host) EV_TRY(hipMemcpyAsync(xpos_host, ev.xpos, sizeof(double) * (size_t)U * 2, hipMemcpyDeviceToHost, st));
+    EV_TRY(hipStreamSynchronize(st));
+    if (profile) {
+        float ms = 0; EV_TRY(hipEventElapsedTime(&ms, e0, e1));
+        *score_ms += ms; *score_launches += 1;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    release();
+#undef EV_TRY
+    return 0;
+}
+
+int eval_run(const DevModel& m, int precision, int32_t* counts_host, double* xpos_host, hipStream_t st, double* score_ms,
+             int64_t* score_launches, bool profile)
+{
+    return precision == REC_F64 ? eval_impl<double>(m, counts_host, xpos_host, st, score_ms, score_launches, profile)
+                                : eval_impl<float>(m, counts_host, xpos_host, st, score_ms, score_launches, profile);
+}
