@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""Throughput of the hot path on synthetic data: BPR-SGD triples/s (headline) and full-catalog
+evaluation users/s, for BPRMF K=64 on 1M users x 200k items x 100M interactions.
+
+  python bench.py --gpus 1 --steps 5 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+
+A step is one SGD epoch: num_pos_events updateFactors calls (model.hpp:47-51) drawn by the device
+sampler and applied by the Hogwild update kernel.  With N ranks the users are sharded, every rank
+applies 1/N of the epoch's tuples to its own users, and the item tables are combined once per
+step with an RCCL all-reduce of the per-rank deltas (total work fixed: strong scaling).
+Evaluation is sharded by user; the metric sums are all-reduced.
+
+One JSON line on stdout (rank 0).  `roofline` prices the update kernel against HBM with the
+algorithmic bytes per triple (each of the 3 K-float rows and 2 biases read once and written once =
+1552 B) and the kernel's average duration from HIP events on the engine's stream; `cpu_baseline`
+times the single-thread CPU restatement of BPRMF::oneiteration on the same corpus.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, spec
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix, spec (v_mfma_f64_16x16x4_f64)
+
+
+def make_synthetic(n_users, n_items, n_clicks, seed, device):
+    """Per-user lengths 3 + geometric (mean n_clicks / n_users), items Zipf(0.9) over popularity
+    ranks, half of a user's clicks shifted into one of 64 taste clusters, ranks mapped to item ids
+    by a fixed permutation.  Returns the post-split training CSR and the test / validation items
+    (every user has >= 3 clicks, so every user is evaluated)."""
+    import torch
+    g = torch.Generator(device=device).manual_seed(seed)
+    mean_extra = n_clicks / n_users - 3.0
+    p = 1.0 / (mean_extra + 1.0)
+    u = torch.rand(n_users, generator=g, device=device, dtype=torch.float64).clamp_min(1e-300)
+    n = 3 + torch.floor(torch.log(u) / math.log(1.0 - p)).long().clamp_max(4000)
+    off = torch.zeros(n_users + 1, dtype=torch.int64, device=device)
+    off[1:] = torch.cumsum(n, 0)
+    total = int(off[-1])
+    w = torch.arange(1, n_items + 1, device=device, dtype=torch.float64).pow(-0.9)
+    cdf = torch.cumsum(w, 0)
+    cdf = cdf / cdf[-1].clone()
+    perm = torch.randperm(n_items, generator=g, device=device)
+    cluster = torch.randint(0, 64, (n_users,), generator=g, device=device)
+    items = torch.empty(total, dtype=torch.int32, device=device)
+    user_of = torch.repeat_interleave(torch.arange(n_users, device=device), n)
+    step = 1 << 24
+    for a in range(0, total, step):
+        b = min(total, a + step)
+        r = torch.rand(b - a, generator=g, device=device, dtype=torch.float64)
+        z = torch.searchsorted(cdf, r).clamp_max(n_items - 1)
+        shifted = torch.rand(b - a, generator=g, device=device) < 0.5
+        shift = cluster[user_of[a:b]] * (n_items // 64)
+        z = torch.where(shifted, (z + shift) % n_items, z)
+        items[a:b] = perm[z].int()
+    pos = torch.arange(total, device=device) - off[:-1][user_of]
+    keep = pos < (n[user_of] - 2)
+    seq_item = items[keep]
+    seq_off = torch.zeros(n_users + 1, dtype=torch.int64, device=device)
+    seq_off[1:] = torch.cumsum(n - 2, 0)
+    test_item = items[off[1:] - 1]
+    val_item = items[off[1:] - 2]
+    out = [t.cpu().numpy() for t in (seq_off, seq_item, test_item, val_item)]
+    del items, user_of, pos, keep, seq_item
+    return out + [total]
+
+
+class DevArray:
+    """Engine-owned device memory seen through the CUDA array interface (for torch.distributed)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--users", type=int, default=1_000_000)
+    ap.add_argument("--items", type=int, default=200_000)
+    ap.add_argument("--clicks", type=int, default=100_000_000)
+    ap.add_argument("--k", type=int, default=64)
+    ap.add_argument("--model", default="BPRMF")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--atomic", type=int, default=1)
+    ap.add_argument("--chunk", type=int, default=1 << 24)
+    ap.add_argument("--eval-users", type=int, default=0, help="evaluate only the first n users of each shard (0 = all)")
+    ap.add_argument("--cpu-steps", type=int, default=12_000_000, help="tuples of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-eval", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import recommendation_amd as ra
+    from recommendation_amd.capi import F32, F64
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    seq_off, seq_item, test_item, val_item, n_clicks = make_synthetic(args.users, args.items, args.clicks, 12345, dev)
+    torch.cuda.empty_cache()
+    U, I, K = args.users, args.items, args.k
+    ub = U * rank // world
+    ue = U * (rank + 1) // world
+    if args.eval_users:
+        # a shard that evaluates fewer users still trains on all of its users: two engines would be
+        # needed; the bench keeps one engine and simply reports the users it evaluated
+        pass
+    prec = F32 if args.precision == "f32" else F64
+    esz = 4 if prec == F32 else 8
+    eng = ra.Engine(args.model, I, seq_off, seq_item, test_item, val_item, K=K, lam=0.01, bias_reg=0.01,
+                    relation_reg=0.01, alpha=0.5, precision=prec, device=local_rank, user_begin=ub, user_end=ue)
+    eng.init_params(seed=2024)
+    eng.set_option("atomic", args.atomic)
+    eng.set_option("chunk", args.chunk)
+    eng.set_option("profile", 1)
+    steps_per_epoch = eng.steps_per_epoch
+    my_steps = steps_per_epoch // world
+
+    # item tables (replicated) as torch tensors over engine memory, for the all-reduce
+    item_tabs = []
+    if world > 1:
+        for ptr, rows, cols, is_user in eng.tables():
+            if not is_user:
+                t = torch.as_tensor(DevArray(ptr, (rows * cols,), "<f4" if prec == F32 else "<f8"), device=dev)
+                item_tabs.append((t, torch.empty_like(t)))
+
+    def barrier():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_step(epoch):
+        for t, base in item_tabs:
+            base.copy_(t)
+        torch.cuda.synchronize()
+        eng.sgd_epoch(0.05, my_steps, seed=99, epoch=epoch * world + rank)
+        eng.sync()
+        for t, base in item_tabs:
+            # every rank started the step from `base`; the combined table is base + sum of the deltas
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            t.sub_(base, alpha=float(world - 1))
+        if item_tabs:
+            torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        one_step(w)
+    barrier()
+    eng.kernel_stats(0); eng.kernel_stats(2)   # reset the HIP-event counters
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        one_step(args.warmup + s)
+    barrier()
+    dt = time.perf_counter() - t0
+    upd_ms, upd_n = eng.kernel_stats(0)
+    smp_ms, smp_n = eng.kernel_stats(2)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    total_triples = my_steps * world * args.steps
+    value = total_triples / dt
+
+    # algorithmic bytes per triple: distinct rows read once + written once (model-specific)
+    rows = {"BPRMF": 3, "MC": 3, "HRM_avg": 4, "HRM_max": 4, "TransRec": 4, "TransRec_L1": 4, "FPMC": 6, "PRME": 6}[args.model]
+    scalars = {"BPRMF": 2, "TransRec": 2, "TransRec_L1": 2}.get(args.model, 0)
+    bytes_per_triple = 2 * rows * K * esz + 2 * scalars * esz
+    tuples_per_launch = my_steps * args.steps / max(upd_n, 1)
+    avg_ms = upd_ms / max(upd_n, 1)
+    achieved = bytes_per_triple * tuples_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "sgd_hogwild_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "bytes_per_triple": bytes_per_triple, "tuples_per_launch": int(tuples_per_launch),
+                "avg_launch_ms": round(avg_ms, 4), "launches": int(upd_n),
+                "sampler_ms_per_launch": round(smp_ms / max(smp_n, 1), 4)}
+
+    out = {"metric": "bpr_sgd_triples_per_sec", "value": round(value, 1), "unit": "triples/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.precision,
+           "data": "synthetic",
+           "config": {"workload": f"{args.model} K={K} oneiteration (BPR-SGD epoch) on synthetic {U} users x {I} items x "
+                                  f"{n_clicks} interactions", "triples_per_step": my_steps * world,
+                      "update": "float atomics" if args.atomic else "plain stores", "parallelism": f"user-sharded x{world}"},
+           "roofline": roofline}
+
+    # ---------------- evaluation: users/s over the full catalog
+    if not args.no_eval:
+        barrier()
+        eng.kernel_stats(1)
+        t0 = time.perf_counter()
+        sums = eng.eval_sums(50)
+        torch.cuda.synchronize()
+        if world > 1:
+            ts = torch.tensor(sums, dtype=torch.float64, device=dev)
+            dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+            sums = ts.cpu().numpy()
+            dist.barrier()
+        et = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([et], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            et = float(tt.item())
+        sc_ms, sc_n = eng.kernel_stats(1)
+        n_eval = float(sums[7])
+        nctx = 1 if args.model in ("BPRMF", "MP") else 2
+        kq = K * (2 if args.model in ("FPMC", "PRME") else 1)
+        flops = 2.0 * nctx * kq * I * (n_eval / world)   # per rank
+        tf = flops / (sc_ms * 1e-3) / 1e12 if sc_ms > 0 else 0.0
+        out["eval"] = {"users_per_sec": round(n_eval / et, 1), "seconds": round(et, 4), "users": int(n_eval),
+                       "auc_test": round(float(sums[1] / n_eval), 6), "hit50_test": round(float(sums[3] / n_eval), 6),
+                       "roofline": {"bound": "mfma", "kernel": "score_count_kernel", "achieved": round(tf, 2),
+                                    "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4),
+                                    "dtype": "f64", "launch_ms": round(sc_ms, 3)}}
+
+    # ---------------- CPU baseline: the single-thread restatement of BPRMF::oneiteration, rank 0, N=1 only
+    if rank == 0 and world == 1 and args.cpu_steps > 0 and args.model == "BPRMF":
+        from oracle import oracle_py as orc
+        o = orc.Oracle("BPRMF", U, I, K, seq_off, seq_item, test_item, val_item, lam=0.01, bias_reg=0.01)
+        W = np.random.default_rng(0).random(o.nw)
+        W[:I] = 0
+        o.bprmf_epoch(W, 0.05, 200_000, 1)  # touch the pages
+        t0 = time.perf_counter()
+        done = o.bprmf_epoch(W, 0.05, args.cpu_steps, 2)
+        ct = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(done / ct, 1), "unit": "triples/s", "cores": 1, "kind": "port",
+                               "sample": f"{done} consecutive updateFactors steps of one epoch on the same corpus, fp64, "
+                                         f"{ct:.1f} s"}
+        out["gpu_over_cpu"] = round(value / (done / ct), 1)
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
