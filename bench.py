@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--k", type=int, default=64)
     ap.add_argument("--model", default="BPRMF")
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--atomic", type=int, default=1)
+    ap.add_argument("--policy", type=int, default=-1, help="update_policy: 0 exact atomics, 1 hybrid, 2 plain stores; -1 = engine default")
     ap.add_argument("--chunk", type=int, default=1 << 24)
     ap.add_argument("--eval-users", type=int, default=0, help="evaluate only the first n users of each shard (0 = all)")
     ap.add_argument("--cpu-steps", type=int, default=12_000_000, help="tuples of the CPU baseline sample (0 = skip)")
@@ -131,7 +131,9 @@ def main():
     eng = ra.Engine(args.model, I, seq_off, seq_item, test_item, val_item, K=K, lam=0.01, bias_reg=0.01,
                     relation_reg=0.01, alpha=0.5, precision=prec, device=local_rank, user_begin=ub, user_end=ue)
     eng.init_params(seed=2024)
-    eng.set_option("atomic", args.atomic)
+    if args.policy >= 0:
+        eng.set_option("update_policy", args.policy)
+    policy = args.policy if args.policy >= 0 else (1 if eng.steps_per_epoch >= (1 << 22) else 0)
     eng.set_option("chunk", args.chunk)
     eng.set_option("profile", 1)
     steps_per_epoch = eng.steps_per_epoch
@@ -202,7 +204,7 @@ def main():
            "data": "synthetic",
            "config": {"workload": f"{args.model} K={K} oneiteration (BPR-SGD epoch) on synthetic {U} users x {I} items x "
                                   f"{n_clicks} interactions", "triples_per_step": my_steps * world,
-                      "update": "float atomics" if args.atomic else "plain stores", "parallelism": f"user-sharded x{world}"},
+                      "update": ["float atomics on every row", "float atomics on item rows and biases (plain stores for user rows and for items holding >= 1/1024 of the positives)", "plain stores"][policy], "parallelism": f"user-sharded x{world}"},
            "roofline": roofline}
 
     # ---------------- evaluation: users/s over the full catalog

@@ -35,6 +35,7 @@ struct DevModel {
     const int32_t* eval_users;          // users of this engine's shard that have a test item
     int n_eval;
     const int32_t* train_count;         // [I] occurrences of each item in the training sequences (MostPopular)
+    const uint8_t* hot;                 // [I+1] 1 = item whose rows are not scattered with atomics (see rec_set_option "hot_count")
 };
 
 // table indices, in the flat order of each model's getParametersFromVector / parametersToFlatVector
@@ -69,6 +70,7 @@ int launch_sampler(const DevModel& m, int4* tuples, int64_t n, int64_t first_ste
 int launch_convert_in(const double* src, void* dst, int64_t n, int precision, hipStream_t st);
 int launch_convert_out(const void* src, double* dst, int64_t n, int precision, hipStream_t st);
 int launch_param_init(const DevModel& m, int precision, uint64_t seed, hipStream_t st);
+int launch_mark_hot(const DevModel& m, uint8_t* hot, int64_t min_count, hipStream_t st);
 
 // Full-catalog evaluation of the users in m.eval_users.  counts_host: [U][3] (count_val, count_test,
 // max; -1 for users not evaluated); xpos_host (optional): [U][2] (x_test, x_val).

@@ -26,12 +26,15 @@ struct rec_engine {
     void* bestW = nullptr;   // copyBestModel snapshot
     double* stage = nullptr; // f64 staging for upload / download
     int64_t stage_elems = 0;
-    int4* tuples = nullptr;  // tuple buffer of the current chunk(s)
+    int4* tuples = nullptr;  // two tuple buffers of `tuples_cap` each: chunk c+1 is sampled while chunk c is applied
     int64_t tuples_cap = 0;
+    hipStream_t st2 = nullptr;                 // sampler stream
+    hipEvent_t ev_sampled[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
+    bool consumed_valid[2] = {false, false};
     std::vector<void*> owned;
     // options
     int64_t chunk = 1 << 22;
-    int atomic = 1;
+    int atomic = 0x1ff;  // bit r: row r of a tuple is scattered with float atomics; bit 8: the biases
     int profile = 0;
     // hip-event statistics: 0 update, 1 score, 2 sampler
     double ms[3] = {0, 0, 0};
@@ -208,7 +211,10 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     m.n_elig = (int)elig.size(); m.n_eval = (int)eval_users.size();
     auto fail = [&](int code) { rec_destroy(e); return code; };
     if (rc) return fail(rc);
-    if (hipStreamCreate(&e->st) != hipSuccess) { rec_set_error("hipStreamCreate failed"); return fail(-2); }
+    if (hipStreamCreate(&e->st) != hipSuccess || hipStreamCreate(&e->st2) != hipSuccess) { rec_set_error("hipStreamCreate failed"); return fail(-2); }
+    for (int b = 0; b < 2; b++)
+        if (hipEventCreateWithFlags(&e->ev_sampled[b], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e->ev_consumed[b], hipEventDisableTiming) != hipSuccess) { rec_set_error("hipEventCreate failed"); return fail(-2); }
     if (hipMalloc(&e->W, e->dev_elems * e->elem_size) != hipSuccess || hipMalloc(&e->bestW, e->dev_elems * e->elem_size) != hipSuccess) {
         rec_set_error("hipMalloc of the parameter tables failed"); return fail(-2);
     }
@@ -219,6 +225,12 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     if (hipMalloc(&g, 8 * (REC_MAX_K + 2 * REC_MAX_L + 8)) != hipSuccess) { rec_set_error("hipMalloc failed"); return fail(-2); }
     e->owned.push_back(g); (void)hipMemset(g, 0, 8 * (REC_MAX_K + 2 * REC_MAX_L + 8));
     m.gacc = g;
+    void* hot = nullptr;
+    if (hipMalloc(&hot, I + 64) != hipSuccess) { rec_set_error("hipMalloc failed"); return fail(-2); }
+    e->owned.push_back(hot); (void)hipMemset(hot, 0, I + 64);
+    m.hot = (const uint8_t*)hot;
+    // scatter policy: exact sums for small problems, the hybrid for large ones (see rec_set_option)
+    rec_set_option(e, "update_policy", e->steps_per_epoch >= (1 << 22) ? 1 : 0);
     *out = e;
     return 0;
 }
@@ -228,6 +240,9 @@ extern "C" int rec_destroy(rec_engine* e)
     if (!e) return 0;
     (void)hipSetDevice(e->desc.device);
     if (e->st) (void)hipStreamSynchronize(e->st);
+    if (e->st2) (void)hipStreamSynchronize(e->st2);
+    for (int b = 0; b < 2; b++) { if (e->ev_sampled[b]) (void)hipEventDestroy(e->ev_sampled[b]); if (e->ev_consumed[b]) (void)hipEventDestroy(e->ev_consumed[b]); }
+    if (e->st2) (void)hipStreamDestroy(e->st2);
     for (int w = 0; w < 3; w++) for (auto& p : e->pending[w]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (void* p : e->owned) (void)hipFree(p);
     if (e->W) (void)hipFree(e->W);
@@ -243,6 +258,7 @@ extern "C" int rec_sync(rec_engine* e)
 {
     if (!e) { rec_set_error("null engine"); return -1; }
     ENG_HIP(hipSetDevice(e->desc.device));
+    ENG_HIP(hipStreamSynchronize(e->st2));
     ENG_HIP(hipStreamSynchronize(e->st));
     return 0;
 }
@@ -328,12 +344,14 @@ extern "C" int rec_restore_best(rec_engine* e)
 
 static int ensure_tuples(rec_engine* e, int64_t n)
 {
+    ENG_HIP(hipStreamSynchronize(e->st2));
     if (e->tuples_cap >= n) return 0;
     ENG_HIP(hipStreamSynchronize(e->st));
     if (e->tuples) (void)hipFree(e->tuples);
     e->tuples = nullptr; e->tuples_cap = 0;
-    ENG_HIP(hipMalloc((void**)&e->tuples, sizeof(int4) * n));
+    ENG_HIP(hipMalloc((void**)&e->tuples, sizeof(int4) * n * 2));
     e->tuples_cap = n;
+    e->consumed_valid[0] = e->consumed_valid[1] = false;
     return 0;
 }
 
@@ -424,17 +442,27 @@ extern "C" int rec_sgd_epoch(rec_engine* e, double lr, int64_t n_steps, uint64_t
     if (n_steps <= 0) return 0;
     ENG_HIP(hipSetDevice(e->desc.device));
     const int64_t chunk = std::min(e->chunk, n_steps);
-    if (int rc = ensure_tuples(e, chunk)) return rc;
+    if (e->tuples_cap < chunk) { if (int rc = ensure_tuples(e, chunk)) return rc; }
     hipEvent_t a = nullptr, b = nullptr;
-    for (int64_t o = 0; o < n_steps; o += chunk) {
+    int c = 0;
+    for (int64_t o = 0; o < n_steps; o += chunk, c++) {
         const int64_t len = std::min(chunk, n_steps - o);
-        if (int rc = ev_begin(e, 2, &a, &b)) return rc;
-        if (int rc = launch_sampler(e->dm, e->tuples, len, o, seed, epoch, e->st)) return rc;
-        if (int rc = ev_end(e, 2, a, b)) return rc;
+        const int buf = c & 1;
+        int4* tb = e->tuples + (int64_t)buf * e->tuples_cap;
+        // sampler stream: the buffer must have been consumed by the update that last read it
+        if (e->consumed_valid[buf]) ENG_HIP(hipStreamWaitEvent(e->st2, e->ev_consumed[buf], 0));
+        if (e->profile) { ENG_HIP(hipEventCreate(&a)); ENG_HIP(hipEventCreate(&b)); ENG_HIP(hipEventRecord(a, e->st2)); }
+        if (int rc = launch_sampler(e->dm, tb, len, o, seed, epoch, e->st2)) return rc;
+        if (e->profile) { ENG_HIP(hipEventRecord(b, e->st2)); e->pending[2].push_back({a, b}); }
+        ENG_HIP(hipEventRecord(e->ev_sampled[buf], e->st2));
+        // update stream
+        ENG_HIP(hipStreamWaitEvent(e->st, e->ev_sampled[buf], 0));
         if (int rc = ev_begin(e, 0, &a, &b)) return rc;
-        if (int rc = launch_sgd_hogwild(e->dm, e->desc.precision, e->tuples, len, lr, e->atomic, e->st)) return rc;
+        if (int rc = launch_sgd_hogwild(e->dm, e->desc.precision, tb, len, lr, e->atomic, e->st)) return rc;
         if (int rc = ev_end(e, 0, a, b)) return rc;
         if (int rc = launch_apply_global(e->dm, e->desc.precision, lr, len, e->st)) return rc;
+        ENG_HIP(hipEventRecord(e->ev_consumed[buf], e->st));
+        e->consumed_valid[buf] = true;
     }
     return 0;
 }
@@ -524,8 +552,26 @@ extern "C" int rec_set_option(rec_engine* e, const char* name, int64_t value)
     if (!e || !name) { rec_set_error("null argument"); return -1; }
     const std::string s(name);
     if (s == "chunk") { if (value < 1) { rec_set_error("chunk must be positive"); return -1; } e->chunk = value; }
-    else if (s == "atomic") e->atomic = value != 0;
+    else if (s == "atomic") e->atomic = value == 1 ? 0x1ff : (int)value;  // 1 = every row; else a mask: bit r = row r of the tuple, bit 8 = biases
     else if (s == "profile") e->profile = value != 0;
+    else if (s == "update_policy") {
+        // 0 exact: every row and bias is scattered with float atomics (sums of all contributions);
+        // 1 hybrid: rows indexed by user are stored plainly (a user is rarely in flight twice), item rows and
+        //   biases use atomics, except for the few items drawn so often (>= 1/1024 of the positives) that
+        //   their atomics would serialize on one address - those are stored plainly too;
+        // 2 plain: classic racy Hogwild stores everywhere
+        if (value == 0) { e->atomic = 0x1ff; return rec_set_option(e, "hot_count", 0); }
+        if (value == 2) { e->atomic = 0; return rec_set_option(e, "hot_count", 0); }
+        if (value != 1) { rec_set_error("update_policy must be 0, 1 or 2"); return -1; }
+        e->atomic = e->desc.model == REC_MC ? 0x1ff : 0x1fe;
+        return rec_set_option(e, "hot_count", std::max<int64_t>(1, e->steps_per_epoch / 1024));
+    }
+    else if (s == "hot_count") {
+        // items with at least `value` training occurrences are "hot" (0 = none)
+        ENG_HIP(hipSetDevice(e->desc.device));
+        if (int rc = launch_mark_hot(e->dm, (uint8_t*)e->dm.hot, value, e->st)) return rc;
+        ENG_HIP(hipStreamSynchronize(e->st));
+    }
     else { rec_set_error("unknown option " + s); return -1; }
     return 0;
 }

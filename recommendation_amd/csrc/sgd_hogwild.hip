@@ -1,9 +1,14 @@
-// Hogwild BPR-SGD step: one lane group (16, 32 or 64 lanes of a wavefront) per tuple.
+// Hogwild BPR-SGD step: one lane group (16, 32 or 64 lanes of a wavefront) per tuple, B tuples in
+// flight per group.
 //
 // Lane g of a group owns components k = g, g+LPT, ... of every row the tuple names, so each row
 // is read with one coalesced wave-instruction per EPL step (a 64-component f32 row = one 256-B
 // request) and written back the same way: as hardware float atomics (one contiguous dword run per
 // row, the shape global_atomic_add_f32 sustains its full rate on), or as plain racy stores.
+// The loop is software-pipelined against HBM latency: while the rows of batch i are turned into
+// deltas, the tuple indices of batch i+2 and the rows of batch i+1 are already in flight, and the
+// atomics of batch i are issued behind them (vector-memory operations retire in issue order, so a
+// wait for the next rows never waits for these atomics).
 // All gradients of a tuple are computed from the values loaded at its start (the reference reads
 // pre-update copies in the same places; where it does not, the difference is O(lr^2)).
 // Rows that every tuple touches (TransRec's r) are not scattered per tuple: their gradients are
@@ -18,258 +23,326 @@ __device__ __forceinline__ void scatter(T* p, T delta, T oldv, int atomic)
     else *p = oldv + delta;
 }
 
-template <class T, int LPT, int EPL>
-struct Grp {
-    int g;  // lane within the group
-    __device__ Grp() : g(threadIdx.x & (LPT - 1)) {}
-    __device__ __forceinline__ void load(const T* row, int K, T (&v)[EPL]) const
-    {
-#pragma unroll
-        for (int j = 0; j < EPL; j++) { int k = g + LPT * j; v[j] = k < K ? row[k] : (T)0; }
-    }
-    __device__ __forceinline__ void add(T* row, int K, const T (&d)[EPL], const T (&old)[EPL], int atomic) const
-    {
-#pragma unroll
-        for (int j = 0; j < EPL; j++) { int k = g + LPT * j; if (k < K) scatter(row + k, d[j], old[j], atomic); }
-    }
-    __device__ __forceinline__ static T sum(T v) { return group_sum<LPT>(v); }
-    // value held by the group's lane 0
-    __device__ __forceinline__ static T first(T v) { return __shfl(v, 0, LPT); }
-};
-
 template <class T> __device__ __forceinline__ T sigmoid_neg(T x) { return (T)1 / ((T)1 + rexp(x)); }
 
-// ------------------------------------------------------------------------------------------------
+// ---- which rows a tuple names: R rows (table, row index, width) and up to two bias scalars
+template <int MODEL> struct Spec;
+template <> struct Spec<REC_BPRMF> { static constexpr int R = 3, NB = 2; };
+template <> struct Spec<REC_MC> { static constexpr int R = 3, NB = 0; };
+template <> struct Spec<REC_FPMC> { static constexpr int R = 6, NB = 0; };
+template <> struct Spec<REC_PRME> { static constexpr int R = 6, NB = 0; };
+template <> struct Spec<REC_HRM_AVG> { static constexpr int R = 4, NB = 0; };
+template <> struct Spec<REC_HRM_MAX> { static constexpr int R = 4, NB = 0; };
+template <> struct Spec<REC_TRANSREC> { static constexpr int R = 4, NB = 2; };
+template <> struct Spec<REC_TRANSREC_L1> { static constexpr int R = 4, NB = 2; };
+
+template <int MODEL, class T>
+__device__ __forceinline__ T* row_ptr(const DevModel& m, const int4& t, int r, int& width)
+{
+    const int K = m.K, KK = m.KK;
+    width = K;
+    if constexpr (MODEL == REC_BPRMF) {           // (u, pos, neg): gamma_u, gamma_pos, gamma_neg
+        return r == 0 ? (T*)m.tab[BPRMF_GU] + (int64_t)t.x * K : (T*)m.tab[BPRMF_GI] + (int64_t)(r == 1 ? t.y : t.z) * K;
+    } else if constexpr (MODEL == REC_MC) {       // (i, pos, neg): gamma_i, eta_pos, eta_neg
+        return r == 0 ? (T*)m.tab[MC_GI] + (int64_t)t.x * K : (T*)m.tab[MC_ETA] + (int64_t)(r == 1 ? t.y : t.z) * K;
+    } else if constexpr (MODEL == REC_FPMC) {     // (u, prev, pos, neg): gamma_u, gamma_pos, gamma_neg, kappa_prev, eta_pos, eta_neg
+        if (r == 0) return (T*)m.tab[FPMC_GU] + (int64_t)t.x * K;
+        if (r < 3) return (T*)m.tab[FPMC_GI] + (int64_t)(r == 1 ? t.z : t.w) * K;
+        width = KK;
+        if (r == 3) return (T*)m.tab[FPMC_KAPPA] + (int64_t)t.y * KK;
+        return (T*)m.tab[FPMC_ETA] + (int64_t)(r == 4 ? t.z : t.w) * KK;
+    } else if constexpr (MODEL == REC_PRME) {     // (u, prev, pos, neg): gamma_u, gamma_pos, gamma_neg, eta_prev, eta_pos, eta_neg
+        if (r == 0) return (T*)m.tab[PRME_GU] + (int64_t)t.x * K;
+        if (r < 3) return (T*)m.tab[PRME_GI] + (int64_t)(r == 1 ? t.z : t.w) * K;
+        width = KK;
+        return (T*)m.tab[PRME_ETA] + (int64_t)(r == 3 ? t.y : r == 4 ? t.z : t.w) * KK;
+    } else if constexpr (MODEL == REC_HRM_AVG || MODEL == REC_HRM_MAX) {  // (u, prev, pos, neg): U_u, V_prev, V_pos, V_neg
+        return r == 0 ? (T*)m.tab[HRM_U] + (int64_t)t.x * K : (T*)m.tab[HRM_V] + (int64_t)(r == 1 ? t.y : r == 2 ? t.z : t.w) * K;
+    } else {                                      // TransRec (u, x, y, yn): R_u, H_x, H_y, H_yn
+        return r == 0 ? (T*)m.tab[TR_R] + (int64_t)t.x * K : (T*)m.tab[TR_H] + (int64_t)(r == 1 ? t.y : r == 2 ? t.z : t.w) * K;
+    }
+}
+
+// item behind row r of the tuple (-1: the row is indexed by user)
+template <int MODEL>
+__device__ __forceinline__ int row_item(const int4& t, int r)
+{
+    if constexpr (MODEL == REC_BPRMF) return r == 0 ? -1 : r == 1 ? t.y : t.z;
+    else if constexpr (MODEL == REC_MC) return r == 0 ? t.x : r == 1 ? t.y : t.z;
+    else if constexpr (MODEL == REC_FPMC || MODEL == REC_PRME) return r == 0 ? -1 : (r == 1 || r == 4) ? t.z : (r == 2 || r == 5) ? t.w : t.y;
+    else return r == 0 ? -1 : r == 1 ? t.y : r == 2 ? t.z : t.w;   // HRM, TransRec
+}
+
+template <int MODEL, class T>
+__device__ __forceinline__ T* bias_ptr(const DevModel& m, const int4& t, int s)
+{
+    if constexpr (MODEL == REC_BPRMF) return (T*)m.tab[BPRMF_BETA] + (s == 0 ? t.y : t.z);
+    else return (T*)m.tab[TR_BETA] + (s == 0 ? t.z : t.w);
+}
+
+// ---- the step itself: rows v[R][EPL] and biases b[2] in, deltas out (in place)
 template <int MODEL, class T, int LPT, int EPL>
+__device__ __forceinline__ T step(const DevModel& m, T lr, int g, T (&v)[Spec<MODEL>::R][EPL], T b0, T b1,
+                                  const T (&rg)[EPL], T (&racc)[EPL])
+{
+    const T lam = (T)m.lambda;
+    auto gsum = [](T x) { return group_sum<LPT>(x); };
+    if constexpr (MODEL == REC_BPRMF) {
+        // BPRMF.cpp:85-105
+        T s = 0;
+#pragma unroll
+        for (int j = 0; j < EPL; j++) s += v[0][j] * (v[1][j] - v[2][j]);
+        const T deri = sigmoid_neg((b0 - b1) + gsum(s));
+#pragma unroll
+        for (int j = 0; j < EPL; j++) {
+            const T u = v[0][j], p = v[1][j], q = v[2][j];
+            v[0][j] = lr * (deri * (p - q) - lam * u);
+            v[1][j] = lr * (deri * u - lam * p);
+            v[2][j] = lr * (-deri * u - lam / (T)10.0 * q);
+        }
+        return deri;
+    } else if constexpr (MODEL == REC_MC) {
+        // MC.cpp:91-110
+        T s = 0;
+#pragma unroll
+        for (int j = 0; j < EPL; j++) s += v[0][j] * (v[1][j] - v[2][j]);
+        const T deri = sigmoid_neg(gsum(s));
+#pragma unroll
+        for (int j = 0; j < EPL; j++) {
+            const T u = v[0][j], p = v[1][j], q = v[2][j];
+            v[0][j] = lr * (deri * (p - q) - lam * u);
+            v[1][j] = lr * (deri * u - lam * p);
+            v[2][j] = lr * (-deri * u - lam * q);
+        }
+        return deri;
+    } else if constexpr (MODEL == REC_FPMC) {
+        // FPMC.cpp:88-122
+        T s = 0;
+#pragma unroll
+        for (int j = 0; j < EPL; j++) s += v[0][j] * (v[1][j] - v[2][j]) + v[3][j] * (v[4][j] - v[5][j]);
+        const T deri = sigmoid_neg(gsum(s));
+#pragma unroll
+        for (int j = 0; j < EPL; j++) {
+#pragma unroll
+            for (int h = 0; h < 6; h += 3) {
+                const T u = v[h][j], p = v[h + 1][j], q = v[h + 2][j];
+                v[h][j] = lr * (deri * (p - q) - lam * u);
+                v[h + 1][j] = lr * (deri * u - lam * p);
+                v[h + 2][j] = lr * (-deri * u - lam * q);
+            }
+        }
+        return deri;
+    } else if constexpr (MODEL == REC_PRME) {
+        // PRME.cpp:82-103; x_uij = -(distance to pos) + (distance to neg)
+        const T alpha = (T)m.alpha;
+        T s = 0;
+#pragma unroll
+        for (int j = 0; j < EPL; j++) {
+            s += alpha * ((v[0][j] - v[2][j]) * (v[0][j] - v[2][j]) - (v[0][j] - v[1][j]) * (v[0][j] - v[1][j]));
+            s += (1 - alpha) * ((v[3][j] - v[5][j]) * (v[3][j] - v[5][j]) - (v[3][j] - v[4][j]) * (v[3][j] - v[4][j]));
+        }
+        const T deri = sigmoid_neg(gsum(s));
+#pragma unroll
+        for (int j = 0; j < EPL; j++) {
+#pragma unroll
+            for (int h = 0; h < 6; h += 3) {
+                const T w = h == 0 ? alpha : 1 - alpha;
+                const T u = v[h][j], p = v[h + 1][j], q = v[h + 2][j];
+                v[h][j] = lr * (deri * w * (p - q) - lam * u);
+                v[h + 1][j] = lr * (deri * w * (u - p) - lam * p);
+                v[h + 2][j] = lr * (deri * (-w) * (u - q) - lam * q);
+            }
+        }
+        return deri;
+    } else if constexpr (MODEL == REC_HRM_AVG || MODEL == REC_HRM_MAX) {
+        // HRM_avg.cpp:168-195, HRM_max.cpp:178-208
+        T h[EPL]; T s = 0;
+#pragma unroll
+        for (int j = 0; j < EPL; j++) {
+            h[j] = MODEL == REC_HRM_MAX ? (v[0][j] > v[1][j] ? v[0][j] : v[1][j]) : (v[0][j] + v[1][j]);
+            s += h[j] * (v[2][j] - v[3][j]);
+        }
+        const T deri = sigmoid_neg(gsum(s));
+#pragma unroll
+        for (int j = 0; j < EPL; j++) {
+            const T u = v[0][j], a = v[1][j], p = v[2][j], q = v[3][j];
+            const T deri_k = deri * (p - q);
+            const bool upd_u = MODEL == REC_HRM_AVG || u > a;
+            v[0][j] = upd_u ? lr * (deri_k - lam * u) : (T)0;
+            v[1][j] = (MODEL == REC_HRM_AVG || !upd_u) ? lr * (deri_k - lam * a) : (T)0;
+            v[2][j] = lr * (deri * h[j] - lam * p);
+            v[3][j] = lr * (-deri * h[j] - lam * q);
+        }
+        return deri;
+    } else {
+        // TransRec.cpp:208-258, TransRec_L1.cpp:207-259
+        constexpr bool L1 = MODEL == REC_TRANSREC_L1;
+        const T rreg = (T)m.relation_reg;
+        T d[EPL], dn[EPL]; T zs = 0;
+#pragma unroll
+        for (int j = 0; j < EPL; j++) {
+            d[j] = rg[j] + v[0][j] + v[1][j] - v[2][j];
+            dn[j] = rg[j] + v[0][j] + v[1][j] - v[3][j];
+            zs += L1 ? (rabs(d[j]) - rabs(dn[j])) : (d[j] * d[j] - dn[j] * dn[j]);
+        }
+        const T deri = sigmoid_neg((-b0 + b1) - gsum(zs));
+        // new item rows, then their projection onto the unit ball (TransRec.cpp:237-239);
+        // padded lanes (k >= K) hold zeros and stay zero
+        T nx[EPL], ny[EPL], nn[EPL]; T sx = 0, sy = 0, sn = 0;
+#pragma unroll
+        for (int j = 0; j < EPL; j++) {
+            const bool live = g + LPT * j < m.K;
+            T gx, gy, gn, gr;
+            if (!L1) {
+                gx = deri * 2 * (-d[j] + dn[j]) - lam * v[1][j];
+                gn = deri * 2 * (-dn[j]) - lam * v[3][j];
+                gy = deri * 2 * (d[j]) - lam * v[2][j];
+                gr = deri * 2 * (-d[j] + dn[j]);
+            } else {
+                const T tmp = (T)((d[j] > 0 ? -1 : 1) + (dn[j] > 0 ? 1 : -1));
+                gx = deri * tmp;
+                gy = deri * (T)(d[j] > 0 ? 1 : -1);
+                gn = deri * (T)(dn[j] > 0 ? -1 : 1);
+                gr = deri * tmp;
+            }
+            if (!live) { gx = gy = gn = gr = 0; }
+            nx[j] = v[1][j] + lr * gx; ny[j] = v[2][j] + lr * gy; nn[j] = v[3][j] + lr * gn;
+            racc[j] += gr;
+            sx += nx[j] * nx[j]; sy += ny[j] * ny[j]; sn += nn[j] * nn[j];
+            d[j] = lr * (gr - rreg * v[0][j]);
+        }
+        sx = rsqrt_(gsum(sx)); sy = rsqrt_(gsum(sy)); sn = rsqrt_(gsum(sn));
+#pragma unroll
+        for (int j = 0; j < EPL; j++) {
+            if (sx > 1) nx[j] /= sx;
+            if (sy > 1) ny[j] /= sy;
+            if (sn > 1) nn[j] /= sn;
+            v[1][j] = nx[j] - v[1][j]; v[2][j] = ny[j] - v[2][j]; v[3][j] = nn[j] - v[3][j];
+            v[0][j] = d[j];
+        }
+        return deri;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int MODEL, class T, int LPT, int EPL, int B>
 __global__ void __launch_bounds__(256) sgd_hogwild_kernel(DevModel m, const int4* __restrict__ tuples, int64_t n, T lr,
                                                          int atomic)
 {
-    const Grp<T, LPT, EPL> G;
+    constexpr int R = Spec<MODEL>::R, NB = Spec<MODEL>::NB;
+    constexpr bool TR = MODEL == REC_TRANSREC || MODEL == REC_TRANSREC_L1;
+    const int g = threadIdx.x & (LPT - 1);
     const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x / LPT);
     const int64_t gid = (int64_t)blockIdx.x * (blockDim.x / LPT) + threadIdx.x / LPT;
-    const int K = m.K, KK = m.KK;
-    const T lam = (T)m.lambda, breg = (T)m.bias_reg;
+    const int64_t nbatch = (n + B - 1) / B;
 
-    // TransRec: gradient of the global translation r, summed over this thread's tuples
-    T racc[EPL];
+    T racc[EPL], rg[EPL];
 #pragma unroll
-    for (int j = 0; j < EPL; j++) racc[j] = 0;
+    for (int j = 0; j < EPL; j++) { racc[j] = 0; rg[j] = 0; }
+    if constexpr (TR) {
+        // the global translation r is read once: it does not change during a launch
+#pragma unroll
+        for (int j = 0; j < EPL; j++) { const int k = g + LPT * j; if (k < m.K) rg[j] = ((const T*)m.tab[TR_r])[k]; }
+    }
 
-    for (int64_t i = gid; i < n; i += ngroups) {
-        const int4 t = tuples[i];
-        if constexpr (MODEL == REC_BPRMF) {
-            // BPRMF.cpp:85-105
-            T* beta = (T*)m.tab[BPRMF_BETA];
-            T* gu = (T*)m.tab[BPRMF_GU] + (int64_t)t.x * K;
-            T* gp = (T*)m.tab[BPRMF_GI] + (int64_t)t.y * K;
-            T* gn = (T*)m.tab[BPRMF_GI] + (int64_t)t.z * K;
-            T u[EPL], p[EPL], q[EPL];
-            G.load(gu, K, u); G.load(gp, K, p); G.load(gn, K, q);
-            T bp = 0, bn = 0;
-            if (G.g == 0) { bp = beta[t.y]; bn = beta[t.z]; }
-            T s = 0;
+    auto load_idx = [&](int64_t batch, int4 (&tp)[B]) {
 #pragma unroll
-            for (int j = 0; j < EPL; j++) s += u[j] * (p[j] - q[j]);
-            s = G.sum(s);
-            const T deri = sigmoid_neg(G.first(bp - bn) + s);
-            T du[EPL], dp[EPL], dq[EPL];
+        for (int b = 0; b < B; b++) {
+            const int64_t i = batch * B + b;
+            tp[b] = (batch < nbatch && i < n) ? tuples[i] : make_int4(-1, 0, 0, 0);
+        }
+    };
+    // bias s of tuple b is held by lane 2b+s of the group: one load and one scatter instruction per batch
+    auto my_bias_ptr = [&](const int4 (&tp)[B]) -> T* {
+        T* p = nullptr;
+        if constexpr (NB == 2) {
 #pragma unroll
-            for (int j = 0; j < EPL; j++) {
-                du[j] = lr * (deri * (p[j] - q[j]) - lam * u[j]);
-                dp[j] = lr * (deri * u[j] - lam * p[j]);
-                dq[j] = lr * (-deri * u[j] - lam / (T)10.0 * q[j]);
+            for (int b = 0; b < B; b++)
+                if ((g >> 1) == b && g < 2 * B && tp[b].x >= 0) p = bias_ptr<MODEL, T>(m, tp[b], g & 1);
+        }
+        return p;
+    };
+    auto load_rows = [&](const int4 (&tp)[B], T (&v)[B][R][EPL], T& bs) {
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            const bool ok = tp[b].x >= 0;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                int width; const T* row = row_ptr<MODEL, T>(m, tp[b], r, width);
+#pragma unroll
+                for (int j = 0; j < EPL; j++) { const int k = g + LPT * j; v[b][r][j] = (ok && k < width) ? row[k] : (T)0; }
             }
-            G.add(gu, K, du, u, atomic); G.add(gp, K, dp, p, atomic); G.add(gn, K, dq, q, atomic);
-            if (G.g == 0) {
-                scatter(beta + t.y, lr * (deri - breg * bp), bp, atomic);
-                scatter(beta + t.z, lr * (-deri - breg * bn), bn, atomic);
-            }
-        } else if constexpr (MODEL == REC_MC) {
-            // MC.cpp:91-110
-            T* gi = (T*)m.tab[MC_GI] + (int64_t)t.x * K;
-            T* ep = (T*)m.tab[MC_ETA] + (int64_t)t.y * K;
-            T* en = (T*)m.tab[MC_ETA] + (int64_t)t.z * K;
-            T u[EPL], p[EPL], q[EPL];
-            G.load(gi, K, u); G.load(ep, K, p); G.load(en, K, q);
-            T s = 0;
+        }
+        bs = 0;
+        if constexpr (NB == 2) { const T* p = my_bias_ptr(tp); if (p) bs = *p; }
+    };
+
+    int4 tp[B], tn[B];
+    T v[B][R][EPL], bs;
+    load_idx(gid, tp);
+    load_idx(gid + ngroups, tn);
+    load_rows(tp, v, bs);
+    for (int64_t batch = gid; batch < nbatch; batch += ngroups) {
+        // indices two batches ahead, rows one batch ahead
+        int4 tnn[B];
+        load_idx(batch + 2 * ngroups, tnn);
+        T vn[B][R][EPL], bn;
+        load_rows(tn, vn, bn);
+        // keep the values the plain-store mode adds its deltas to
+        T old[B][R][EPL]; T mine = 0;  // mine: deri of the tuple whose bias this lane holds
 #pragma unroll
-            for (int j = 0; j < EPL; j++) s += u[j] * (p[j] - q[j]);
-            const T deri = sigmoid_neg(G.sum(s));
-            T du[EPL], dp[EPL], dq[EPL];
+        for (int b = 0; b < B; b++) {
 #pragma unroll
-            for (int j = 0; j < EPL; j++) {
-                du[j] = lr * (deri * (p[j] - q[j]) - lam * u[j]);
-                dp[j] = lr * (deri * u[j] - lam * p[j]);
-                dq[j] = lr * (-deri * u[j] - lam * q[j]);
-            }
-            G.add(gi, K, du, u, atomic); G.add(ep, K, dp, p, atomic); G.add(en, K, dq, q, atomic);
-        } else if constexpr (MODEL == REC_FPMC) {
-            // FPMC.cpp:88-122
-            T* gu = (T*)m.tab[FPMC_GU] + (int64_t)t.x * K;
-            T* gp = (T*)m.tab[FPMC_GI] + (int64_t)t.z * K;
-            T* gn = (T*)m.tab[FPMC_GI] + (int64_t)t.w * K;
-            T* ka = (T*)m.tab[FPMC_KAPPA] + (int64_t)t.y * KK;
-            T* ep = (T*)m.tab[FPMC_ETA] + (int64_t)t.z * KK;
-            T* en = (T*)m.tab[FPMC_ETA] + (int64_t)t.w * KK;
-            T u[EPL], p[EPL], q[EPL], a[EPL], b[EPL], c[EPL];
-            G.load(gu, K, u); G.load(gp, K, p); G.load(gn, K, q);
-            G.load(ka, KK, a); G.load(ep, KK, b); G.load(en, KK, c);
-            T s = 0;
+            for (int r = 0; r < R; r++)
 #pragma unroll
-            for (int j = 0; j < EPL; j++) s += u[j] * (p[j] - q[j]) + a[j] * (b[j] - c[j]);
-            const T deri = sigmoid_neg(G.sum(s));
-            T d0[EPL], d1[EPL], d2[EPL];
+                for (int j = 0; j < EPL; j++) old[b][r][j] = v[b][r][j];
+            const T b0 = NB == 2 ? __shfl(bs, 2 * b, LPT) : (T)0, b1 = NB == 2 ? __shfl(bs, 2 * b + 1, LPT) : (T)0;
+            const T deri = step<MODEL, T, LPT, EPL>(m, lr, g, v[b], b0, b1, rg, racc);
+            if ((g >> 1) == b) mine = deri;
+        }
 #pragma unroll
-            for (int j = 0; j < EPL; j++) {
-                d0[j] = lr * (deri * (p[j] - q[j]) - lam * u[j]);
-                d1[j] = lr * (deri * u[j] - lam * p[j]);
-                d2[j] = lr * (-deri * u[j] - lam * q[j]);
-            }
-            G.add(gu, K, d0, u, atomic); G.add(gp, K, d1, p, atomic); G.add(gn, K, d2, q, atomic);
+        for (int b = 0; b < B; b++) {
+            if (tp[b].x < 0) continue;
 #pragma unroll
-            for (int j = 0; j < EPL; j++) {
-                d0[j] = lr * (deri * (b[j] - c[j]) - lam * a[j]);
-                d1[j] = lr * (deri * a[j] - lam * b[j]);
-                d2[j] = lr * (-deri * a[j] - lam * c[j]);
-            }
-            G.add(ka, KK, d0, a, atomic); G.add(ep, KK, d1, b, atomic); G.add(en, KK, d2, c, atomic);
-        } else if constexpr (MODEL == REC_PRME) {
-            // PRME.cpp:82-103
-            const T alpha = (T)m.alpha;
-            T* gu = (T*)m.tab[PRME_GU] + (int64_t)t.x * K;
-            T* gp = (T*)m.tab[PRME_GI] + (int64_t)t.z * K;
-            T* gn = (T*)m.tab[PRME_GI] + (int64_t)t.w * K;
-            T* ei = (T*)m.tab[PRME_ETA] + (int64_t)t.y * KK;
-            T* ep = (T*)m.tab[PRME_ETA] + (int64_t)t.z * KK;
-            T* en = (T*)m.tab[PRME_ETA] + (int64_t)t.w * KK;
-            T u[EPL], p[EPL], q[EPL], a[EPL], b[EPL], c[EPL];
-            G.load(gu, K, u); G.load(gp, K, p); G.load(gn, K, q);
-            G.load(ei, KK, a); G.load(ep, KK, b); G.load(en, KK, c);
-            T s = 0;  // x_uij = -(dist to pos) + (dist to neg)
+            for (int r = 0; r < R; r++) {
+                int width; T* row = row_ptr<MODEL, T>(m, tp[b], r, width);
+                const int it = row_item<MODEL>(tp[b], r);
+                // rows of hot items fall back to plain stores: their atomics would serialize on one address
+                const int at = ((atomic >> r) & 1) && !(it >= 0 && m.hot[it]);
 #pragma unroll
-            for (int j = 0; j < EPL; j++) {
-                s += alpha * ((u[j] - q[j]) * (u[j] - q[j]) - (u[j] - p[j]) * (u[j] - p[j]));
-                s += (1 - alpha) * ((a[j] - c[j]) * (a[j] - c[j]) - (a[j] - b[j]) * (a[j] - b[j]));
+                for (int j = 0; j < EPL; j++) { const int k = g + LPT * j; if (k < width) scatter(row + k, v[b][r][j], old[b][r][j], at); }
             }
-            const T deri = sigmoid_neg(G.sum(s));
-            T d0[EPL], d1[EPL], d2[EPL];
+        }
+        if constexpr (NB == 2) {
+            // BPRMF.cpp:92-93: +deri on the positive, -deri on the negative; TransRec.cpp:225-226: the opposite signs
+            T* p = my_bias_ptr(tp);
+            if (p) {
+                const T sgn = ((g & 1) == 0) == (MODEL == REC_BPRMF) ? (T)1 : (T)-1;
+                const T* base = (const T*)m.tab[MODEL == REC_BPRMF ? BPRMF_BETA : TR_BETA];
+                scatter(p, lr * (sgn * mine - (T)m.bias_reg * bs), bs, ((atomic >> 8) & 1) && !m.hot[p - base]);
+            }
+        }
+        bs = bn;
 #pragma unroll
-            for (int j = 0; j < EPL; j++) {
-                d0[j] = lr * (deri * alpha * (p[j] - q[j]) - lam * u[j]);
-                d1[j] = lr * (deri * alpha * (u[j] - p[j]) - lam * p[j]);
-                d2[j] = lr * (deri * (-alpha) * (u[j] - q[j]) - lam * q[j]);
-            }
-            G.add(gu, K, d0, u, atomic); G.add(gp, K, d1, p, atomic); G.add(gn, K, d2, q, atomic);
+        for (int b = 0; b < B; b++) {
+            tp[b] = tn[b]; tn[b] = tnn[b];
 #pragma unroll
-            for (int j = 0; j < EPL; j++) {
-                d0[j] = lr * (deri * (1 - alpha) * (b[j] - c[j]) - lam * a[j]);
-                d1[j] = lr * (deri * (1 - alpha) * (a[j] - b[j]) - lam * b[j]);
-                d2[j] = lr * (deri * (alpha - 1) * (a[j] - c[j]) - lam * c[j]);
-            }
-            G.add(ei, KK, d0, a, atomic); G.add(ep, KK, d1, b, atomic); G.add(en, KK, d2, c, atomic);
-        } else if constexpr (MODEL == REC_HRM_AVG || MODEL == REC_HRM_MAX) {
-            // HRM_avg.cpp:168-195, HRM_max.cpp:178-208
-            T* Uu = (T*)m.tab[HRM_U] + (int64_t)t.x * K;
-            T* Vp = (T*)m.tab[HRM_V] + (int64_t)t.y * K;
-            T* Vi = (T*)m.tab[HRM_V] + (int64_t)t.z * K;
-            T* Vn = (T*)m.tab[HRM_V] + (int64_t)t.w * K;
-            T u[EPL], a[EPL], p[EPL], q[EPL], h[EPL];
-            G.load(Uu, K, u); G.load(Vp, K, a); G.load(Vi, K, p); G.load(Vn, K, q);
-            T s = 0;
+            for (int r = 0; r < R; r++)
 #pragma unroll
-            for (int j = 0; j < EPL; j++) {
-                h[j] = MODEL == REC_HRM_MAX ? (u[j] > a[j] ? u[j] : a[j]) : (u[j] + a[j]);
-                s += h[j] * (p[j] - q[j]);
-            }
-            const T deri = sigmoid_neg(G.sum(s));
-            T d0[EPL], d1[EPL], d2[EPL], d3[EPL];
-#pragma unroll
-            for (int j = 0; j < EPL; j++) {
-                const T deri_k = deri * (p[j] - q[j]);
-                d2[j] = lr * (deri * h[j] - lam * p[j]);
-                d3[j] = lr * (-deri * h[j] - lam * q[j]);
-                const bool upd_u = MODEL == REC_HRM_AVG || u[j] > a[j];
-                const bool upd_p = MODEL == REC_HRM_AVG || !(u[j] > a[j]);
-                d0[j] = upd_u ? lr * (deri_k - lam * u[j]) : (T)0;
-                d1[j] = upd_p ? lr * (deri_k - lam * a[j]) : (T)0;
-            }
-            G.add(Vi, K, d2, p, atomic); G.add(Vn, K, d3, q, atomic);
-            G.add(Uu, K, d0, u, atomic); G.add(Vp, K, d1, a, atomic);
-        } else if constexpr (MODEL == REC_TRANSREC || MODEL == REC_TRANSREC_L1) {
-            // TransRec.cpp:208-258, TransRec_L1.cpp:207-259
-            constexpr bool L1 = MODEL == REC_TRANSREC_L1;
-            const T rreg = (T)m.relation_reg;
-            T* beta = (T*)m.tab[TR_BETA];
-            T* R = (T*)m.tab[TR_R] + (int64_t)t.x * K;
-            T* Hx = (T*)m.tab[TR_H] + (int64_t)t.y * K;
-            T* Hy = (T*)m.tab[TR_H] + (int64_t)t.z * K;
-            T* Hn = (T*)m.tab[TR_H] + (int64_t)t.w * K;
-            T r[EPL], u[EPL], x[EPL], y[EPL], yn[EPL], v[EPL], vn[EPL];
-            G.load((T*)m.tab[TR_r], K, r); G.load(R, K, u); G.load(Hx, K, x); G.load(Hy, K, y); G.load(Hn, K, yn);
-            T by = 0, bn = 0;
-            if (G.g == 0) { by = beta[t.z]; bn = beta[t.w]; }
-            T zs = 0;
-#pragma unroll
-            for (int j = 0; j < EPL; j++) {
-                v[j] = r[j] + u[j] + x[j] - y[j];
-                vn[j] = r[j] + u[j] + x[j] - yn[j];
-                zs += L1 ? (rabs(v[j]) - rabs(vn[j])) : (v[j] * v[j] - vn[j] * vn[j]);
-            }
-            const T z = G.first(-by + bn) - G.sum(zs);
-            const T deri = sigmoid_neg(z);
-            // new rows, then the unit-ball projection of the three item rows (TransRec.cpp:237-239);
-            // padded lanes (k >= K) hold zeros and stay zero
-            T nx[EPL], ny[EPL], nn[EPL], du[EPL];
-            T sx = 0, sy = 0, sn = 0;
-#pragma unroll
-            for (int j = 0; j < EPL; j++) {
-                const bool live = G.g + LPT * j < K;
-                T gx, gy, gn_, gr;
-                if (!L1) {
-                    gx = deri * 2 * (-v[j] + vn[j]) - lam * x[j];
-                    gn_ = deri * 2 * (-vn[j]) - lam * yn[j];
-                    gy = deri * 2 * (v[j]) - lam * y[j];
-                    gr = deri * 2 * (-v[j] + vn[j]);
-                } else {
-                    const T tmp = (T)((v[j] > 0 ? -1 : 1) + (vn[j] > 0 ? 1 : -1));
-                    gx = deri * tmp;
-                    gy = deri * (T)(v[j] > 0 ? 1 : -1);
-                    gn_ = deri * (T)(vn[j] > 0 ? -1 : 1);
-                    gr = deri * tmp;
-                }
-                if (!live) { gx = gy = gn_ = gr = 0; }
-                nx[j] = x[j] + lr * gx; ny[j] = y[j] + lr * gy; nn[j] = yn[j] + lr * gn_;
-                du[j] = lr * (gr - rreg * u[j]);
-                racc[j] += gr;
-                sx += nx[j] * nx[j]; sy += ny[j] * ny[j]; sn += nn[j] * nn[j];
-            }
-            sx = rsqrt_(G.sum(sx)); sy = rsqrt_(G.sum(sy)); sn = rsqrt_(G.sum(sn));
-#pragma unroll
-            for (int j = 0; j < EPL; j++) {
-                if (sx > 1) nx[j] /= sx;
-                if (sy > 1) ny[j] /= sy;
-                if (sn > 1) nn[j] /= sn;
-                nx[j] -= x[j]; ny[j] -= y[j]; nn[j] -= yn[j];
-            }
-            G.add(Hx, K, nx, x, atomic); G.add(Hy, K, ny, y, atomic); G.add(Hn, K, nn, yn, atomic);
-            G.add(R, K, du, u, atomic);
-            if (G.g == 0) {
-                scatter(beta + t.z, lr * (-deri - breg * by), by, atomic);
-                scatter(beta + t.w, lr * (deri - breg * bn), bn, atomic);
-            }
+                for (int j = 0; j < EPL; j++) v[b][r][j] = vn[b][r][j];
         }
     }
 
-    if constexpr (MODEL == REC_TRANSREC || MODEL == REC_TRANSREC_L1) {
+    if constexpr (TR) {
         // block-level sum of the r gradients: component k lives in lane (k % LPT) of every group
         __shared__ T red[REC_MAX_K];
         for (int k = threadIdx.x; k < REC_MAX_K; k += blockDim.x) red[k] = 0;
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < EPL; j++) { int k = G.g + LPT * j; if (k < K) unsafeAtomicAdd(&red[k], racc[j]); }
+        for (int j = 0; j < EPL; j++) { const int k = g + LPT * j; if (k < m.K) unsafeAtomicAdd(&red[k], racc[j]); }
         __syncthreads();
         T* gacc = (T*)m.gacc;
-        for (int k = threadIdx.x; k < K; k += blockDim.x) unsafeAtomicAdd(gacc + k, red[k]);
+        for (int k = threadIdx.x; k < m.K; k += blockDim.x) unsafeAtomicAdd(gacc + k, red[k]);
     }
 }
 
@@ -295,18 +368,20 @@ template <int MODEL, class T>
 static int dispatch_shape(const DevModel& m, const int4* tuples, int64_t n, double lr, int atomic, hipStream_t st)
 {
     const int Kmax = m.K > m.KK ? m.K : m.KK;
-    // 2048 blocks of 256 threads keep 8 blocks per CU resident; groups stride over the tuples
-    auto go = [&](auto kern, int lpt) {
-        int64_t groups_per_block = 256 / lpt;
-        int64_t blocks = (n + groups_per_block - 1) / groups_per_block;
+    // 2048 blocks of 256 threads keep 8 blocks per CU resident; groups stride over the batches
+    auto go = [&](auto kern, int lpt, int b) {
+        const int64_t groups_per_block = 256 / lpt;
+        int64_t blocks = ((n + b - 1) / b + groups_per_block - 1) / groups_per_block;
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, m, tuples, n, (T)lr, atomic);
     };
-    if (Kmax <= 16) go(sgd_hogwild_kernel<MODEL, T, 16, 1>, 16);
-    else if (Kmax <= 32) go(sgd_hogwild_kernel<MODEL, T, 32, 1>, 32);
-    else if (Kmax <= 64) go(sgd_hogwild_kernel<MODEL, T, 64, 1>, 64);
-    else if (Kmax <= 128) go(sgd_hogwild_kernel<MODEL, T, 64, 2>, 64);
-    else if (Kmax <= 256) go(sgd_hogwild_kernel<MODEL, T, 64, 4>, 64);
+    constexpr int R = Spec<MODEL>::R;
+    constexpr int B1 = R <= 4 ? 4 : 2;  // tuples in flight per group, by register budget
+    if (Kmax <= 16) go(sgd_hogwild_kernel<MODEL, T, 16, 1, B1>, 16, B1);
+    else if (Kmax <= 32) go(sgd_hogwild_kernel<MODEL, T, 32, 1, B1>, 32, B1);
+    else if (Kmax <= 64) go(sgd_hogwild_kernel<MODEL, T, 64, 1, B1>, 64, B1);
+    else if (Kmax <= 128) go(sgd_hogwild_kernel<MODEL, T, 64, 2, 2>, 64, 2);
+    else if (Kmax <= 256) go(sgd_hogwild_kernel<MODEL, T, 64, 4, 1>, 64, 1);
     else { rec_set_error("K > 256 is not supported"); return -1; }
     HIP_TRY(hipGetLastError());
     return 0;
