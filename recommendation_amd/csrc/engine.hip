@@ -34,6 +34,8 @@ struct rec_engine {
     std::vector<void*> owned;
     // options
     int64_t chunk = 1 << 22;
+    int64_t global_window = 1 << 18;
+    int64_t stale_window = 0;   // tuples per launch so that a row rarely receives more than a couple of stale updates (0 = no limit)
     int atomic = 0x1ff;  // bit r: row r of a tuple is scattered with float atomics; bit 8: the biases
     int profile = 0;
     // hip-event statistics: 0 update, 1 score, 2 sampler
@@ -229,6 +231,20 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     if (hipMalloc(&hot, I + 64) != hipSuccess) { rec_set_error("hipMalloc failed"); return fail(-2); }
     e->owned.push_back(hot); (void)hipMemset(hot, 0, I + 64);
     m.hot = (const uint8_t*)hot;
+    // All tuples of one launch may be computed from the same parameter values.  With a small catalog a launch is
+    // therefore kept short enough that an item row receives about two updates per launch on average; with a
+    // large catalog the number of tuples the chip has in flight (tens of thousands) is below that bound anyway.
+    {
+        double rows = 2;
+        switch (d->model) {
+        case REC_MC: case REC_HRM_AVG: case REC_HRM_MAX: case REC_TRANSREC: case REC_TRANSREC_L1: rows = 3; break;
+        case REC_FPMC: case REC_PRME: rows = 5; break;
+        case REC_FOSSIL: case REC_FOSSIL_SIMPLE: case REC_REBUS: rows = 2 + (double)E / std::max(1, U); break;
+        default: break;
+        }
+        const int64_t w = (int64_t)(2.0 * I / rows);
+        e->stale_window = w >= 65536 ? 0 : std::max<int64_t>(16, w);
+    }
     // scatter policy: exact sums for small problems, the hybrid for large ones (see rec_set_option)
     rec_set_option(e, "update_policy", e->steps_per_epoch >= (1 << 22) ? 1 : 0);
     *out = e;
@@ -355,6 +371,29 @@ static int ensure_tuples(rec_engine* e, int64_t n)
     return 0;
 }
 
+// Hogwild launches over `n` tuples.  Models with a row that every tuple touches (TransRec's r,
+// Fossil's WT, FossilSimple's alpha) keep that row constant during a launch and fold its summed
+// gradient in afterwards, so their launches are kept short (`global_window` tuples).
+static int launch_update(rec_engine* e, const int4* tuples, int64_t n, double lr)
+{
+    const int model = e->desc.model;
+    const bool history = model == REC_FOSSIL || model == REC_FOSSIL_SIMPLE || model == REC_REBUS;
+    const bool global_row = model == REC_TRANSREC || model == REC_TRANSREC_L1 || model == REC_FOSSIL || model == REC_FOSSIL_SIMPLE;
+    int64_t window = global_row ? e->global_window : n;
+    if (e->stale_window > 0 && e->stale_window < window) window = e->stale_window;
+    for (int64_t o = 0; o < n; o += window) {
+        const int64_t len = std::min(window, n - o);
+        int rc = history ? launch_sgd_history(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic, e->st)
+                         : launch_sgd_hogwild(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic, e->st);
+        if (rc) return rc;
+        if (global_row) {
+            if ((rc = launch_apply_global(e->dm, e->desc.precision, lr, len, e->st))) return rc;
+            if ((rc = launch_apply_global_history(e->dm, e->desc.precision, lr, e->st))) return rc;
+        }
+    }
+    return 0;
+}
+
 // ---- HIP-event bookkeeping: events are recorded around a launch and read back lazily
 static int ev_begin(rec_engine* e, int which, hipEvent_t* a, hipEvent_t* b)
 {
@@ -423,9 +462,8 @@ extern "C" int rec_sgd_replay(rec_engine* e, double lr, const int32_t* tuples, i
         for (int64_t o = 0; o < n; o += e->chunk) {
             const int64_t len = std::min(e->chunk, n - o);
             if (int rc = ev_begin(e, 0, &a, &b)) return rc;
-            if (int rc = launch_sgd_hogwild(e->dm, e->desc.precision, e->tuples + o, len, lr, e->atomic, e->st)) return rc;
+            if (int rc = launch_update(e, e->tuples + o, len, lr)) return rc;
             if (int rc = ev_end(e, 0, a, b)) return rc;
-            if (int rc = launch_apply_global(e->dm, e->desc.precision, lr, len, e->st)) return rc;
         }
         // the host buffer may be reused by the caller: the copy above must have completed
         ENG_HIP(hipStreamSynchronize(e->st));
@@ -458,9 +496,8 @@ extern "C" int rec_sgd_epoch(rec_engine* e, double lr, int64_t n_steps, uint64_t
         // update stream
         ENG_HIP(hipStreamWaitEvent(e->st, e->ev_sampled[buf], 0));
         if (int rc = ev_begin(e, 0, &a, &b)) return rc;
-        if (int rc = launch_sgd_hogwild(e->dm, e->desc.precision, tb, len, lr, e->atomic, e->st)) return rc;
+        if (int rc = launch_update(e, tb, len, lr)) return rc;
         if (int rc = ev_end(e, 0, a, b)) return rc;
-        if (int rc = launch_apply_global(e->dm, e->desc.precision, lr, len, e->st)) return rc;
         ENG_HIP(hipEventRecord(e->ev_consumed[buf], e->st));
         e->consumed_valid[buf] = true;
     }
@@ -554,6 +591,8 @@ extern "C" int rec_set_option(rec_engine* e, const char* name, int64_t value)
     if (s == "chunk") { if (value < 1) { rec_set_error("chunk must be positive"); return -1; } e->chunk = value; }
     else if (s == "atomic") e->atomic = value == 1 ? 0x1ff : (int)value;  // 1 = every row; else a mask: bit r = row r of the tuple, bit 8 = biases
     else if (s == "profile") e->profile = value != 0;
+    else if (s == "stale_window") { if (value < 0) { rec_set_error("stale_window must be >= 0"); return -1; } e->stale_window = value; }
+    else if (s == "global_window") { if (value < 1) { rec_set_error("global_window must be positive"); return -1; } e->global_window = value; }
     else if (s == "update_policy") {
         // 0 exact: every row and bias is scattered with float atomics (sums of all contributions);
         // 1 hybrid: rows indexed by user are stored plainly (a user is rarely in flight twice), item rows and

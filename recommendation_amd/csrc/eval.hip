@@ -123,6 +123,15 @@ __global__ void __launch_bounds__(256) build_queries_kernel(DevModel m, EvalDev 
         xa = -(B.sc(TR_BETA, pos) + B.wsum(d));
         break;
     }
+    case REC_TRANSREC_L1: {  // TransRec_L1.cpp:85-92; scored by the |.|_1 kernel, so q is kept unscaled
+        double d = 0;
+        for (int k = lane; k < K; k += 64) {
+            const double g = B.ld(TR_H, prev, K, k) + B.sc(TR_r, k) + B.ld(TR_R, u, K, k);
+            q[k] = g; d += fabs(g - B.ld(TR_H, pos, K, k));
+        }
+        xa = -(B.sc(TR_BETA, pos) + B.wsum(d));
+        break;
+    }
     case REC_FOSSIL_SIMPLE: case REC_FOSSIL: {
         // FossilSimple.cpp:82-103 through model::AUC; Fossil.cpp:81-117 with the contexts of Fossil.cpp:389-404
         const bool simple = m.model == REC_FOSSIL_SIMPLE;
@@ -242,6 +251,7 @@ __global__ void __launch_bounds__(256) item_consts_kernel(DevModel m, EvalDev ev
     switch (m.model) {
     case REC_MP: b = (double)m.train_count[j]; break;
     case REC_BPRMF: b = B.sc(BPRMF_BETA, j); break;
+    case REC_TRANSREC_L1: b = B.sc(TR_BETA, j); break;
     case REC_FOSSIL_SIMPLE: b = B.sc(FS_BETA, j); break;
     case REC_FOSSIL: b = B.sc(FO_BETA, j); break;
     case REC_PRME: {
@@ -378,6 +388,58 @@ __global__ void __launch_bounds__(256) score_count_kernel(EvalDev ev, const T* _
         }
 }
 
+// |.|_1 scoring (TransRec_L1): not a contraction, so it runs on the vector ALU.  A block owns QT
+// queries for the whole item sweep; items are staged through LDS in tiles of 64 (odd row stride:
+// conflict-free when the 64 lanes of a wavefront read 64 different items), thread (item jj, query
+// group qg) accumulates QT/4 distances per tile.
+template <class T, int QT>
+__global__ void __launch_bounds__(256) score_count_l1_kernel(EvalDev ev, const T* __restrict__ H, const int32_t* __restrict__ qtest,
+                                                             const int32_t* __restrict__ qval, int I, int K)
+{
+    extern __shared__ double lds[];
+    const int STR = K | 1;
+    double* tile = lds;                 // [64][STR]
+    double* qs = lds + 64 * STR;        // [QT][K]
+    const int tid = threadIdx.x, jj = tid & 63, qg = tid >> 6;
+    const int64_t qbase = (int64_t)blockIdx.x * QT;
+    for (int i = tid; i < QT * K; i += 256) qs[i] = ev.Q[(qbase + i / K) * ev.KQ + i % K];
+    double thr[QT / 4]; int ex1[QT / 4], ex2[QT / 4], cnt[QT / 4];
+#pragma unroll
+    for (int a = 0; a < QT / 4; a++) {
+        const int64_t qi = qbase + qg + 4 * a;
+        thr[a] = ev.thr[qi]; ex1[a] = qtest[qi]; ex2[a] = qval[qi]; cnt[a] = 0;
+    }
+    for (int item0 = 0; item0 < I; item0 += 64) {
+        __syncthreads();
+        for (int i = tid; i < 64 * K; i += 256) {
+            const int it = i / K, k = i % K; const int64_t j = (int64_t)item0 + it;
+            tile[it * STR + k] = j < I ? (double)H[j * K + k] : 0.0;
+        }
+        __syncthreads();
+        const int j = item0 + jj;
+        double acc[QT / 4];
+#pragma unroll
+        for (int a = 0; a < QT / 4; a++) acc[a] = 0;
+        for (int k = 0; k < K; k++) {
+            const double t = tile[jj * STR + k];
+#pragma unroll
+            for (int a = 0; a < QT / 4; a++) acc[a] += fabs(qs[(qg + 4 * a) * K + k] - t);
+        }
+        if (j < I) {
+            const double bj = ev.bconst[j];
+#pragma unroll
+            for (int a = 0; a < QT / 4; a++) cnt[a] += (j != ex1[a] && j != ex2[a] && thr[a] > -(bj + acc[a])) ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < QT / 4; a++) {
+        int c = cnt[a];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if (jj == 0) ev.cnt[qbase + qg + 4 * a] = c;
+    }
+}
+
 // Removes the clicked items from the counts and writes (count_val, count_test, max) per user.
 // One wavefront per query; the score of a clicked item is recomputed on the vector ALU.
 template <class T>
@@ -401,9 +463,14 @@ __global__ void __launch_bounds__(256) correct_clicked_kernel(DevModel m, EvalDe
         const int e = clk[i];
         if (e == test || e == val) { dup += (e == test) + (e == val && val != test); continue; }
         double s = 0;
-        for (int k = lane; k < K1; k += 64) s += q[k] * (double)seg0[(int64_t)e * K1 + k];
-        for (int k = lane; k < K2; k += 64) s += q[K1 + k] * (double)seg1[(int64_t)e * K2 + k];
-        s = group_sum<64>(s) + ev.bconst[e];
+        if (m.model == REC_TRANSREC_L1) {
+            for (int k = lane; k < K1; k += 64) s += fabs(q[k] - (double)seg0[(int64_t)e * K1 + k]);
+            s = -(ev.bconst[e] + group_sum<64>(s));
+        } else {
+            for (int k = lane; k < K1; k += 64) s += q[k] * (double)seg0[(int64_t)e * K1 + k];
+            for (int k = lane; k < K2; k += 64) s += q[K1 + k] * (double)seg1[(int64_t)e * K2 + k];
+            s = group_sum<64>(s) + ev.bconst[e];
+        }
         c -= thr > s ? 1 : 0;
         c2 -= thr2 > s ? 1 : 0;
     }
@@ -473,7 +540,7 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
     case REC_FPMC: ev.seg0 = FPMC_GI; ev.K1 = m.K; ev.seg1 = FPMC_ETA; ev.K2 = m.KK; break;
     case REC_PRME: ev.seg0 = PRME_GI; ev.K1 = m.K; ev.seg1 = PRME_ETA; ev.K2 = m.KK; break;
     case REC_HRM_AVG: case REC_HRM_MAX: ev.seg0 = HRM_V; ev.K1 = m.K; break;
-    case REC_TRANSREC: ev.seg0 = TR_H; ev.K1 = m.K; break;
+    case REC_TRANSREC: case REC_TRANSREC_L1: ev.seg0 = TR_H; ev.K1 = m.K; break;
     case REC_FOSSIL_SIMPLE: ev.seg0 = FS_V; ev.K1 = m.K; break;
     case REC_FOSSIL: ev.seg0 = FO_V; ev.K1 = m.K; break;
     case REC_REBUS: ev.seg0 = RB_P; ev.K1 = m.K; break;
@@ -483,7 +550,9 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
     ev.KQ = kw <= 16 ? 16 : kw <= 32 ? 32 : kw <= 64 ? 64 : kw <= 128 ? 128 : 256;
     if (kw > 256) { rec_set_error("query width above 256 is not supported"); return -1; }
     const int mt = ev.KQ <= 32 ? 4 : ev.KQ <= 64 ? 2 : 1;
-    const int qblock = 4 * mt * 16;
+    const bool l1 = m.model == REC_TRANSREC_L1;
+    constexpr int L1_QT = 32;
+    const int qblock = l1 ? L1_QT : 4 * mt * 16;
     ev.nq = m.n_eval * ev.nctx;
     ev.nq_pad = ((ev.nq + qblock - 1) / qblock) * qblock;
 
@@ -520,7 +589,15 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (profile) { EV_TRY(hipEventCreate(&e0)); EV_TRY(hipEventCreate(&e1)); EV_TRY(hipEventRecord(e0, st)); }
-    int rc = ev.nctx == 1 ? launch_score<T, true>(ev, m, qtest, qval, st) : launch_score<T, false>(ev, m, qtest, qval, st);
+    int rc = 0;
+    if (l1) {
+        const size_t lds_bytes = sizeof(double) * ((size_t)64 * (m.K | 1) + (size_t)L1_QT * m.K);
+        hipLaunchKernelGGL((score_count_l1_kernel<T, L1_QT>), dim3((unsigned)(ev.nq_pad / L1_QT)), dim3(256), lds_bytes, st, ev,
+                           (const T*)m.tab[TR_H], qtest, qval, I, m.K);
+        if (hipGetLastError() != hipSuccess) { rec_set_error("launch of the L1 scoring kernel failed"); rc = -2; }
+    } else {
+        rc = ev.nctx == 1 ? launch_score<T, true>(ev, m, qtest, qval, st) : launch_score<T, false>(ev, m, qtest, qval, st);
+    }
     if (rc) { release(); return rc; }
     if (profile) EV_TRY(hipEventRecord(e1, st));
     hipLaunchKernelGGL(correct_clicked_kernel<T>, dim3(blocks_for_waves(ev.nq)), dim3(256), 0, st, m, ev);

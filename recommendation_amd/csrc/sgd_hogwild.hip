@@ -83,7 +83,7 @@ __device__ __forceinline__ T* bias_ptr(const DevModel& m, const int4& t, int s)
 // ---- the step itself: rows v[R][EPL] and biases b[2] in, deltas out (in place)
 template <int MODEL, class T, int LPT, int EPL>
 __device__ __forceinline__ T step(const DevModel& m, T lr, int g, T (&v)[Spec<MODEL>::R][EPL], T b0, T b1,
-                                  const T (&rg)[EPL], T (&racc)[EPL])
+                                  const T (&rg)[EPL], T (&racc)[EPL], const bool (&at)[Spec<MODEL>::R])
 {
     const T lam = (T)m.lambda;
     auto gsum = [](T x) { return group_sum<LPT>(x); };
@@ -178,25 +178,36 @@ __device__ __forceinline__ T step(const DevModel& m, T lr, int g, T (&v)[Spec<MO
         // TransRec.cpp:208-258, TransRec_L1.cpp:207-259
         constexpr bool L1 = MODEL == REC_TRANSREC_L1;
         const T rreg = (T)m.relation_reg;
+        // An item row may sit outside the unit ball while a launch is running (see below): it is read
+        // as its projection, which is what the reference would have stored (TransRec.cpp:245-258).
+        T h[3][EPL];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            T s = 0;
+#pragma unroll
+            for (int j = 0; j < EPL; j++) s += v[r + 1][j] * v[r + 1][j];
+            s = rsqrt_(gsum(s));
+#pragma unroll
+            for (int j = 0; j < EPL; j++) h[r][j] = s > 1 ? v[r + 1][j] / s : v[r + 1][j];
+        }
         T d[EPL], dn[EPL]; T zs = 0;
 #pragma unroll
         for (int j = 0; j < EPL; j++) {
-            d[j] = rg[j] + v[0][j] + v[1][j] - v[2][j];
-            dn[j] = rg[j] + v[0][j] + v[1][j] - v[3][j];
+            d[j] = rg[j] + v[0][j] + h[0][j] - h[1][j];
+            dn[j] = rg[j] + v[0][j] + h[0][j] - h[2][j];
             zs += L1 ? (rabs(d[j]) - rabs(dn[j])) : (d[j] * d[j] - dn[j] * dn[j]);
         }
         const T deri = sigmoid_neg((-b0 + b1) - gsum(zs));
-        // new item rows, then their projection onto the unit ball (TransRec.cpp:237-239);
-        // padded lanes (k >= K) hold zeros and stay zero
-        T nx[EPL], ny[EPL], nn[EPL]; T sx = 0, sy = 0, sn = 0;
+        // padded lanes (k >= K) hold zeros and must stay zero
+        T nw[3][EPL]; T sq[3] = {0, 0, 0};
 #pragma unroll
         for (int j = 0; j < EPL; j++) {
             const bool live = g + LPT * j < m.K;
             T gx, gy, gn, gr;
             if (!L1) {
-                gx = deri * 2 * (-d[j] + dn[j]) - lam * v[1][j];
-                gn = deri * 2 * (-dn[j]) - lam * v[3][j];
-                gy = deri * 2 * (d[j]) - lam * v[2][j];
+                gx = deri * 2 * (-d[j] + dn[j]) - lam * h[0][j];
+                gn = deri * 2 * (-dn[j]) - lam * h[2][j];
+                gy = deri * 2 * (d[j]) - lam * h[1][j];
                 gr = deri * 2 * (-d[j] + dn[j]);
             } else {
                 const T tmp = (T)((d[j] > 0 ? -1 : 1) + (dn[j] > 0 ? 1 : -1));
@@ -206,19 +217,22 @@ __device__ __forceinline__ T step(const DevModel& m, T lr, int g, T (&v)[Spec<MO
                 gr = deri * tmp;
             }
             if (!live) { gx = gy = gn = gr = 0; }
-            nx[j] = v[1][j] + lr * gx; ny[j] = v[2][j] + lr * gy; nn[j] = v[3][j] + lr * gn;
+            nw[0][j] = h[0][j] + lr * gx; nw[1][j] = h[1][j] + lr * gy; nw[2][j] = h[2][j] + lr * gn;
             racc[j] += gr;
-            sx += nx[j] * nx[j]; sy += ny[j] * ny[j]; sn += nn[j] * nn[j];
-            d[j] = lr * (gr - rreg * v[0][j]);
+            sq[0] += nw[0][j] * nw[0][j]; sq[1] += nw[1][j] * nw[1][j]; sq[2] += nw[2][j] * nw[2][j];
+            v[0][j] = lr * (gr - rreg * v[0][j]);
         }
-        sx = rsqrt_(gsum(sx)); sy = rsqrt_(gsum(sy)); sn = rsqrt_(gsum(sn));
+        // A row written with a plain store gets the projected new value (TransRec.cpp:237-239).  A row
+        // scattered with atomics only receives its gradient step: a projection expressed as a delta would be
+        // applied once per tuple in flight and overshoot; launch_apply_global projects every row after the launch.
 #pragma unroll
-        for (int j = 0; j < EPL; j++) {
-            if (sx > 1) nx[j] /= sx;
-            if (sy > 1) ny[j] /= sy;
-            if (sn > 1) nn[j] /= sn;
-            v[1][j] = nx[j] - v[1][j]; v[2][j] = ny[j] - v[2][j]; v[3][j] = nn[j] - v[3][j];
-            v[0][j] = d[j];
+        for (int r = 0; r < 3; r++) {
+            const T s = rsqrt_(gsum(sq[r]));
+#pragma unroll
+            for (int j = 0; j < EPL; j++) {
+                if (at[r + 1]) v[r + 1][j] = nw[r][j] - h[r][j];
+                else v[r + 1][j] = (s > 1 ? nw[r][j] / s : nw[r][j]) - v[r + 1][j];
+            }
         }
         return deri;
     }
@@ -290,6 +304,7 @@ __global__ void __launch_bounds__(256) sgd_hogwild_kernel(DevModel m, const int4
         load_rows(tn, vn, bn);
         // keep the values the plain-store mode adds its deltas to
         T old[B][R][EPL]; T mine = 0;  // mine: deri of the tuple whose bias this lane holds
+        bool at[B][R];
 #pragma unroll
         for (int b = 0; b < B; b++) {
 #pragma unroll
@@ -297,7 +312,13 @@ __global__ void __launch_bounds__(256) sgd_hogwild_kernel(DevModel m, const int4
 #pragma unroll
                 for (int j = 0; j < EPL; j++) old[b][r][j] = v[b][r][j];
             const T b0 = NB == 2 ? __shfl(bs, 2 * b, LPT) : (T)0, b1 = NB == 2 ? __shfl(bs, 2 * b + 1, LPT) : (T)0;
-            const T deri = step<MODEL, T, LPT, EPL>(m, lr, g, v[b], b0, b1, rg, racc);
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                // rows of hot items fall back to plain stores: their atomics would serialize on one address
+                const int it = row_item<MODEL>(tp[b], r);
+                at[b][r] = ((atomic >> r) & 1) && !(tp[b].x >= 0 && it >= 0 && m.hot[it]);
+            }
+            const T deri = step<MODEL, T, LPT, EPL>(m, lr, g, v[b], b0, b1, rg, racc, at[b]);
             if ((g >> 1) == b) mine = deri;
         }
 #pragma unroll
@@ -306,11 +327,8 @@ __global__ void __launch_bounds__(256) sgd_hogwild_kernel(DevModel m, const int4
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 int width; T* row = row_ptr<MODEL, T>(m, tp[b], r, width);
-                const int it = row_item<MODEL>(tp[b], r);
-                // rows of hot items fall back to plain stores: their atomics would serialize on one address
-                const int at = ((atomic >> r) & 1) && !(it >= 0 && m.hot[it]);
 #pragma unroll
-                for (int j = 0; j < EPL; j++) { const int k = g + LPT * j; if (k < width) scatter(row + k, v[b][r][j], old[b][r][j], at); }
+                for (int j = 0; j < EPL; j++) { const int k = g + LPT * j; if (k < width) scatter(row + k, v[b][r][j], old[b][r][j], at[b][r]); }
             }
         }
         if constexpr (NB == 2) {
@@ -349,17 +367,34 @@ __global__ void __launch_bounds__(256) sgd_hogwild_kernel(DevModel m, const int4
 // Folds the summed gradients of the always-touched rows into the parameters after a launch of
 // n tuples.  n sequential steps of the reference move such a row by about lr * (sum of gradients
 // - n * lambda * row) as long as it barely changes; the sum is applied with at most `cap` steps'
-// worth of learning rate so that a large launch cannot overshoot.
+// worth of learning rate so that one launch cannot overshoot the point where the sequential
+// steps would have stopped moving it (the engine keeps launches of these models short instead).
 template <class T>
 __global__ void apply_global_kernel(DevModel m, T lr, int64_t n, T cap)
 {
     T* gacc = (T*)m.gacc;
     const T scale = n > 0 ? ((T)n < cap ? (T)1 : cap / (T)n) : (T)0;
-    if (m.model == REC_TRANSREC || m.model == REC_TRANSREC_L1) {
-        T* r = (T*)m.tab[TR_r];
-        for (int k = threadIdx.x; k < m.K; k += blockDim.x) {
-            r[k] += lr * scale * (gacc[k] - (T)n * (T)m.lambda * r[k]);
-            gacc[k] = 0;
+    T* r = (T*)m.tab[TR_r];
+    for (int k = threadIdx.x; k < m.K; k += blockDim.x) {
+        r[k] += lr * scale * (gacc[k] - (T)n * (T)m.lambda * r[k]);
+        gacc[k] = 0;
+    }
+}
+
+// every item row back onto the unit ball (TransRec.cpp:245-258), one wavefront per row
+template <class T>
+__global__ void __launch_bounds__(256) project_rows_kernel(T* __restrict__ tab, int64_t rows, int K)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = w; r < rows; r += nw) {
+        T* row = tab + r * K; T x[REC_MAX_EPL]; T s = 0;
+#pragma unroll
+        for (int j = 0; j < REC_MAX_EPL; j++) { const int k = lane + 64 * j; x[j] = k < K ? row[k] : (T)0; s += x[j] * x[j]; }
+        s = rsqrt_(group_sum<64>(s));
+        if (s > 1) {
+#pragma unroll
+            for (int j = 0; j < REC_MAX_EPL; j++) { const int k = lane + 64 * j; if (k < K) row[k] = x[j] / s; }
         }
     }
 }
@@ -416,11 +451,16 @@ int launch_sgd_hogwild(const DevModel& m, int precision, const int4* tuples, int
 int launch_apply_global(const DevModel& m, int precision, double lr, int64_t n_tuples, hipStream_t st)
 {
     if (!(m.model == REC_TRANSREC || m.model == REC_TRANSREC_L1)) return 0;
-    const double cap = 256.0;
-    if (precision == REC_F64)
+    const double cap = 16.0;
+    int64_t blocks = ((int64_t)m.I + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    if (precision == REC_F64) {
         hipLaunchKernelGGL(apply_global_kernel<double>, dim3(1), dim3(256), 0, st, m, lr, n_tuples, cap);
-    else
+        hipLaunchKernelGGL(project_rows_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, st, (double*)m.tab[TR_H], (int64_t)m.I, m.K);
+    } else {
         hipLaunchKernelGGL(apply_global_kernel<float>, dim3(1), dim3(256), 0, st, m, (float)lr, n_tuples, (float)cap);
+        hipLaunchKernelGGL(project_rows_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (float*)m.tab[TR_H], (int64_t)m.I, m.K);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }

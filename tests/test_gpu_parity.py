@@ -12,7 +12,7 @@ from tests.golden_util import ML5_TAGS, TOY_MODELS, fixture_case, make_oracle
 pytestmark = pytest.mark.gpu
 
 HOGWILD_MODELS = ["BPRMF", "MC", "FPMC", "PRME", "HRM_avg", "HRM_max", "TransRec", "TransRec_L1"]
-EVAL_MODELS = ["MP", "BPRMF", "MC", "FPMC", "PRME", "HRM_avg", "HRM_max", "TransRec", "FossilSimple", "Fossil", "REBUS"]
+EVAL_MODELS = ["MP"] + TOY_MODELS
 
 
 @pytest.mark.parametrize("model", TOY_MODELS)
@@ -107,6 +107,14 @@ def test_hogwild_equals_sequential_without_collisions(model, prec):
     assert len(chosen) >= 3
     o = make_oracle(g, model, co, ci, labels)
     W0 = g["W0"] if prec == F64 else g["W0"].astype(np.float32).astype(np.float64)
+    if model.startswith("TransRec"):
+        # item rows start inside the unit ball, as they do after TransRec::init and after every step
+        K, I = int(g["K"]), int(g["n_items"])
+        W0 = W0.copy()
+        H = W0[I:I + I * K].reshape(I, K)
+        H /= np.maximum(1.0, np.sqrt((H * H).sum(1, keepdims=True)) * 1.0000001)
+        if prec == F32:
+            W0 = W0.astype(np.float32).astype(np.float64)
     ref = o.replay(W0, chosen, float(g["lr"]))
     e = make_engine(g, model, co, ci, labels, prec)
     e.upload(W0)
@@ -122,6 +130,64 @@ def test_hogwild_equals_sequential_without_collisions(model, prec):
     tol = 1e-10 if prec == F64 else 1e-5
     assert rel_err(W1, ref, floor=1e-1) < tol, (model, rel_err(W1, ref, floor=1e-1))
     e.close()
+
+
+@pytest.mark.parametrize("model", ["FossilSimple", "Fossil", "REBUS"])
+def test_history_hogwild_single_tuples(model):
+    """One tuple per launch: the Hogwild kernels of the history models against updateFactors.
+    When the tuple's history holds no repeated item and its short-term items do not alias the
+    positive / negative the two are the same arithmetic; otherwise the reference's second in-place
+    update of a row sees the first one (an O(lr^2) difference the parallel form does not reproduce)."""
+    g, model, co, ci, labels = fixture_case(model, "toy")
+    o = make_oracle(g, model, co, ci, labels)
+    seq_off, seq_item, test, val = orc.split(co, ci)
+    L = int(g["L"])
+    e = make_engine(g, model, co, ci, labels, F64)
+    e.set_option("update_policy", 0)
+    n_clean = n_alias = 0
+    for t in g["tuples"][:120]:
+        u = int(t[0]); hist = seq_item[seq_off[u]:seq_off[u + 1]].tolist()
+        if model == "FossilSimple":
+            used, pos, neg, prev = hist, int(t[2]), int(t[3]), [int(t[1])]
+        elif model == "Fossil":
+            tp = int(t[1]); used, pos, neg, prev = hist, hist[tp], int(t[2]), hist[max(0, tp - L):tp]
+        else:
+            tp = int(t[1]) + 1; used, pos, neg, prev = hist[:tp], hist[tp], int(t[2]), []
+        clean = (len(set(used)) == len(used) or model == "REBUS") and pos not in prev and neg not in prev
+        ref = o.replay(g["W0"], t[None, :], float(g["lr"]))
+        e.upload(g["W0"])
+        e.sgd_replay(float(g["lr"]), t[None, :], HOGWILD)
+        W1 = e.download()
+        err = rel_err(W1, ref, floor=1e-1)
+        if clean:
+            n_clean += 1
+            assert err < 1e-9, (model, t, err)
+        else:
+            n_alias += 1
+            assert err < 2e-3, (model, t, err)
+    assert n_clean >= 10 and (n_alias >= 1 or model == "REBUS")
+    e.close()
+
+
+@pytest.mark.parametrize("model", TOY_MODELS)
+def test_hogwild_epoch_moves_towards_the_data(model):
+    """A few device epochs (sampler + Hogwild update, both precisions) keep the parameters finite
+    and improve the validation AUC of the toy corpus over its initial value."""
+    g, model, co, ci, labels = fixture_case(model, "toy")
+    for prec in (F32, F64):
+        e = make_engine(g, model, co, ci, labels, prec)
+        e.init_params(3)
+        m0, _, _ = e.eval()
+        for ep in range(30):
+            e.sgd_epoch(0.05, e.steps_per_epoch, seed=11, epoch=ep)
+        e.sync()
+        W = e.download()
+        assert np.isfinite(W).all()
+        m1, counts, _ = e.eval()
+        assert m1.auc_val > m0.auc_val, (model, prec, m0.auc_val, m1.auc_val)
+        _, ref = make_oracle(g, model, co, ci, labels).eval(W)
+        assert np.array_equal(counts, ref)
+        e.close()
 
 
 @pytest.mark.parametrize("model", TOY_MODELS)
