@@ -85,6 +85,10 @@ int64_t rec_nw(const rec_engine* e);
 int rec_params_upload(rec_engine* e, const double* W, int64_t nw);
 int rec_params_download(rec_engine* e, double* W, int64_t nw);
 
+/* a slice W[first, first+n) of the flat parameter vector (what the reference reads as W[i], e.g. the
+ * "r = ..." / "decay_wt_0 = ..." progress lines of TransRec.cpp:112-124 and Fossil.cpp:260) */
+int rec_params_read(rec_engine* e, int64_t first, int64_t n, double* out);
+
 /* replaces: <Model>::init's random fill (e.g. BPRMF.cpp:11-21, TransRec.cpp:14-30) with a
  * counter-based generator of the same distribution */
 int rec_params_init(rec_engine* e, uint64_t seed);

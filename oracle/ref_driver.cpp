@@ -157,9 +157,24 @@ static void finish_simple(M& md)
 	dump_metrics(&md);
 }
 
+// "traj:N:C" in place of the tuples file: N epochs of the model's own oneiteration()/oneIteration(),
+// the model's own AUC() every C epochs; prints "TRAJ iter AUC_val AUC_test HIT_val HIT_test".
+static int g_traj_n = 0, g_traj_c = 0;
+#define TRAJ(md, EPOCH_CALL)                                                                  \
+	do {                                                                                      \
+		for (int it = 1; it <= g_traj_n; it++) {                                              \
+			md.EPOCH_CALL(lr);                                                                \
+			if (it % g_traj_c == 0) {                                                         \
+				double m[7]; md.AUC(&m[0], &m[1], &m[2], &m[3], &m[4], &m[5], &m[6]);         \
+				fprintf(stderr, "TRAJ %d %.6f %.6f %.6f %.6f\n", it, m[0], m[1], m[2], m[3]);  \
+			}                                                                                 \
+		}                                                                                     \
+	} while (0)
+
 int main(int argc, char** argv)
 {
 	if (argc != 14) { fprintf(stderr, "bad usage\n"); return 2; }
+	if (strncmp(argv[11], "traj:", 5) == 0) { sscanf(argv[11], "traj:%d:%d", &g_traj_n, &g_traj_c); argv[11] = (char*)"-"; }
 	string name = argv[1];
 	const char* data_path = argv[2];
 	int K = atoi(argv[3]);
@@ -199,51 +214,61 @@ int main(int argc, char** argv)
 	} else if (name == "BPRMF") {
 		BPRMF md(&corp, K, lambda, bias_reg);
 		md.init(); dump_meta(&md); dump_split(&md); dump_W(&md, ".Winit.f64"); load_W0(&md, w0);
+		if (g_traj_n) { TRAJ(md, oneiteration); return 0; }
 		for (auto& t : tuples) md.updateFactors(t.a, t.b, t.c, lr);
 		dump_W(&md, ".W1.f64"); finish_simple(md);
 	} else if (name == "MC") {
 		MC md(&corp, K, lambda);
 		md.init(); dump_meta(&md); dump_split(&md); dump_W(&md, ".Winit.f64"); load_W0(&md, w0);
+		if (g_traj_n) { TRAJ(md, oneiteration); return 0; }
 		for (auto& t : tuples) md.updateFactors(t.a, t.b, t.c, lr);
 		dump_W(&md, ".W1.f64"); finish_simple(md);
 	} else if (name == "FPMC") {
 		FPMC md(&corp, K, K, lambda);
 		md.init(); dump_meta(&md); dump_split(&md); dump_W(&md, ".Winit.f64"); load_W0(&md, w0);
+		if (g_traj_n) { TRAJ(md, oneiteration); return 0; }
 		for (auto& t : tuples) md.updateFactors(t.a, t.b, t.c, t.d, lr);
 		dump_W(&md, ".W1.f64"); finish_simple(md);
 	} else if (name == "PRME") {
 		PRME md(&corp, K, K, alpha, lambda);
 		md.init(); dump_meta(&md); dump_split(&md); dump_W(&md, ".Winit.f64"); load_W0(&md, w0);
+		if (g_traj_n) { TRAJ(md, oneiteration); return 0; }
 		for (auto& t : tuples) md.updateFactors(t.a, t.b, t.c, t.d, lr);
 		dump_W(&md, ".W1.f64"); finish_simple(md);
 	} else if (name == "HRM_avg") {
 		HRM_avg md(&corp, K, lambda);
 		md.init(); dump_meta(&md); dump_split(&md); dump_W(&md, ".Winit.f64"); load_W0(&md, w0);
+		if (g_traj_n) { TRAJ(md, oneIteration); return 0; }
 		for (auto& t : tuples) { force_next_rand_mod(md.nItems, t.d); md.updateFactors(t.a, t.b, t.c, lr); }
 		dump_W(&md, ".W1.f64"); finish_simple(md);
 	} else if (name == "HRM_max") {
 		HRM_max md(&corp, K, lambda);
 		md.init(); dump_meta(&md); dump_split(&md); dump_W(&md, ".Winit.f64"); load_W0(&md, w0);
+		if (g_traj_n) { TRAJ(md, oneIteration); return 0; }
 		for (auto& t : tuples) { force_next_rand_mod(md.nItems, t.d); md.updateFactors(t.a, t.b, t.c, lr); }
 		dump_W(&md, ".W1.f64"); finish_simple(md);
 	} else if (name == "TransRec") {
 		TransRec md(&corp, K, lambda, relation_reg, bias_reg);
 		md.init(); dump_meta(&md); dump_split(&md); dump_W(&md, ".Winit.f64"); load_W0(&md, w0);
+		if (g_traj_n) { TRAJ(md, oneIteration); return 0; }
 		for (auto& t : tuples) md.updateFactors(t.a, t.b, t.c, t.d, lr);
 		dump_W(&md, ".W1.f64"); finish_simple(md);
 	} else if (name == "TransRec_L1") {
 		TransRec_L1 md(&corp, K, lambda, relation_reg, bias_reg);
 		md.init(); dump_meta(&md); dump_split(&md); dump_W(&md, ".Winit.f64"); load_W0(&md, w0);
+		if (g_traj_n) { TRAJ(md, oneIteration); return 0; }
 		for (auto& t : tuples) md.updateFactors(t.a, t.b, t.c, t.d, lr);
 		dump_W(&md, ".W1.f64"); finish_simple(md);
 	} else if (name == "FossilSimple") {
 		FossilSimple md(&corp, K, lambda, bias_reg);
 		md.init(); dump_meta(&md); dump_split(&md); dump_W(&md, ".Winit.f64"); load_W0(&md, w0);
+		if (g_traj_n) { TRAJ(md, oneiteration); return 0; }
 		for (auto& t : tuples) md.updateFactors(t.a, t.b, t.c, t.d, lr);
 		dump_W(&md, ".W1.f64"); finish_simple(md);
 	} else if (name == "Fossil") {
 		Fossil md(&corp, L, K, lambda, bias_reg);
 		md.init(); dump_meta(&md); dump_split(&md); dump_W(&md, ".Winit.f64"); load_W0(&md, w0);
+		if (g_traj_n) { TRAJ(md, oneiteration); return 0; }
 		// tuple = (user, target position t>=1 in the train sequence, neg, unused);
 		// prev_items as Fossil::oneiteration builds them (Fossil.cpp:266-272).
 		for (auto& t : tuples) {
@@ -272,6 +297,7 @@ int main(int argc, char** argv)
 		REBUS md(&corp, K, lambda, bias_reg, alpha);
 		if (md.loadPST(minCount, L, data_path) != 0) { fprintf(stderr, "no FSUB file\n"); return 3; }
 		md.init(); dump_meta(&md); dump_split(&md); dump_W(&md, ".Winit.f64"); load_W0(&md, w0);
+		if (g_traj_n) { TRAJ(md, oneiteration); return 0; }
 		{
 			vector<double> eta;
 			for (auto& row : md.eta_cumWeibullSoftmax) for (double e : row) eta.push_back(e);

@@ -13,7 +13,7 @@ F32, F64 = 0, 1
 SEQUENTIAL, HOGWILD = 0, 1
 
 EXPORTS = ["rec_last_error", "rec_create", "rec_destroy", "rec_sync", "rec_nw", "rec_params_upload",
-           "rec_params_download", "rec_params_init", "rec_snapshot_best", "rec_restore_best", "rec_sgd_replay",
+           "rec_params_download", "rec_params_read", "rec_params_init", "rec_snapshot_best", "rec_restore_best", "rec_sgd_replay",
            "rec_sgd_epoch", "rec_sample_tuples", "rec_steps_per_epoch", "rec_eval", "rec_eval_sums",
            "rec_rebus_build_paths", "rec_num_tables", "rec_table_info", "rec_set_option", "rec_kernel_stats"]
 
@@ -136,6 +136,11 @@ class Engine:
         W = np.zeros(self.nw, np.float64)
         _check(lib().rec_params_download(self.handle, _p(W), C.c_int64(len(W))))
         return W
+
+    def read_params(self, first, n):
+        out = np.zeros(n, np.float64)
+        _check(lib().rec_params_read(self.handle, C.c_int64(first), C.c_int64(n), _p(out)))
+        return out
 
     def init_params(self, seed):
         _check(lib().rec_params_init(self.handle, C.c_uint64(seed)))

@@ -331,6 +331,25 @@ extern "C" int rec_params_download(rec_engine* e, double* W, int64_t nw)
     return 0;
 }
 
+extern "C" int rec_params_read(rec_engine* e, int64_t first, int64_t n, double* out)
+{
+    if (!e || (!out && n > 0)) { rec_set_error("null argument"); return -1; }
+    if (first < 0 || n < 0 || first + n > e->nw) { rec_set_error("parameter range out of bounds"); return -1; }
+    ENG_HIP(hipSetDevice(e->desc.device));
+    ENG_HIP(hipStreamSynchronize(e->st));
+    if (int rc = ensure_stage(e, std::min<int64_t>(STAGE_ELEMS, std::max<int64_t>(e->nw, 1)))) return rc;
+    for (auto& t : e->tables) {
+        const int64_t a = std::max(first, t.host_off), b = std::min(first + n, t.host_off + t.rows * t.cols);
+        for (int64_t o = a; o < b; o += e->stage_elems) {
+            const int64_t len = std::min(e->stage_elems, b - o);
+            if (int rc = launch_convert_out((char*)e->W + (t.dev_off + (o - t.host_off)) * e->elem_size, e->stage, len, e->desc.precision, e->st)) return rc;
+            ENG_HIP(hipMemcpyAsync(out + (o - first), e->stage, sizeof(double) * len, hipMemcpyDeviceToHost, e->st));
+            ENG_HIP(hipStreamSynchronize(e->st));
+        }
+    }
+    return 0;
+}
+
 extern "C" int rec_params_init(rec_engine* e, uint64_t seed)
 {
     if (!e) { rec_set_error("null engine"); return -1; }

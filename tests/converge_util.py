@@ -1,0 +1,42 @@
+"""The reference's train() policy (validation cadence, best snapshot, patience: e.g. BPRMF.cpp:152-203,
+REBUS.cpp:559-615) driven through the engine's Python binding."""
+import numpy as np
+
+import recommendation_amd as ra
+from oracle import oracle_py as orc
+from recommendation_amd.capi import F32
+from tests.golden_util import ml5_corpus, read_labels
+
+CADENCE = {"REBUS": 100}
+PATIENCE = {"MC": 1000, "FossilSimple": 500}
+
+
+def train_like_reference(r, precision=F32, seed=0, max_epochs=None):
+    co, ci = ml5_corpus()
+    seq_off, seq_item, test, val = orc.split(co, ci)
+    I = int(ci.max()) + 1
+    model = r["model"]
+    po = pi = None
+    if model == "REBUS":
+        labels = read_labels(f"ML1M-atmost-5_root_fsub_minCount_{r['minCount']}_L_{r['L']}.txt.gz")
+        lo, li = orc.parse_labels(labels, I)
+        po, pi = ra.build_rebus_paths(I, seq_off, seq_item, val, lo, li)
+    e = ra.Engine(model, I, seq_off, seq_item, test, val, K=r["K"], L=r["L"], lam=r["lam"], bias_reg=r["bias_reg"],
+                  relation_reg=r["relation_reg"], alpha=r["alpha"], precision=precision, path_off=po, path_item=pi)
+    e.init_params(seed)
+    cadence, patience = CADENCE.get(model, 50), PATIENCE.get(model, 300)
+    best, best_iter, it = -1.0, 0, 0
+    max_epochs = max_epochs or r["max_iterations"]
+    for it in range(1, max_epochs + 1):
+        e.sgd_epoch(0.05, e.steps_per_epoch, seed=seed, epoch=it)
+        if it % cadence == 0 and (model != "REBUS" or it > 49):
+            m, _, _ = e.eval(want_counts=False)
+            if best < m.auc_val:
+                best, best_iter = m.auc_val, it
+                e.snapshot_best()
+            elif it > best_iter + patience:
+                break
+    e.restore_best()
+    m, _, _ = e.eval(want_counts=False)
+    e.close()
+    return dict(auc_test=m.auc_test, auc_val=m.auc_val, hit50_test=m.hit_test, epochs=it, best_iter=best_iter)

@@ -1,0 +1,98 @@
+"""The ./train CLI (reference's 13 positional arguments, src/main.cpp:142-231) on the HIP engine:
+known answer of MostPopular, progress / result lines, saved-model format, REBUS label loading."""
+import gzip
+import os
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.golden_util import GOLD, fixture_case, make_oracle
+from oracle import oracle_py as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TRAIN = os.path.join(ROOT, "recommendation_amd", "train")
+ML5 = "ML1M-atmost-5"
+
+
+@pytest.fixture(scope="module")
+def workdir(tmp_path_factory):
+    w = tmp_path_factory.mktemp("cli")
+    for d in ("01-Data", "96-FSUB", "03-Models"):
+        os.makedirs(w / d)
+    with gzip.open(os.path.join(GOLD, ML5 + ".txt.gz"), "rb") as f, open(w / "01-Data" / (ML5 + ".txt"), "wb") as g:
+        shutil.copyfileobj(f, g)
+    # the loader reads gzip as well (the reference goes through igzstream)
+    shutil.copy(os.path.join(GOLD, ML5 + ".txt.gz"), w / "01-Data" / (ML5 + "z.txt"))
+    for tag in ("minCount_1_L_1", "minCount_2_L_3"):
+        fn = f"{ML5}_root_fsub_{tag}.txt"
+        with gzip.open(os.path.join(GOLD, fn + ".gz"), "rb") as f, open(w / "96-FSUB" / fn, "wb") as g:
+            shutil.copyfileobj(f, g)
+    return w
+
+
+def run(workdir, *args, expect=0):
+    r = subprocess.run([TRAIN] + [str(a) for a in args], cwd=workdir, capture_output=True, text=True, timeout=300)
+    assert r.returncode == expect, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+def parse_saved(path):
+    txt = open(path).read()
+    nw = int(txt.split('"NW":')[1].split(",")[0])
+    vals = np.array([float(v) for v in txt.split('"W": [')[1].split("]")[0].split(",")])
+    assert len(vals) == nw
+    assert txt.startswith('{\n  "NW": ') and txt.endswith("]\n}\n")
+    return vals
+
+
+def test_usage_exits_with_1_without_a_gpu_call():
+    r = subprocess.run([TRAIN, "x"], capture_output=True, text=True)
+    assert r.returncode == 1 and "13. Model name" in r.stdout
+
+
+@pytest.mark.gpu
+def test_most_popular_known_answer(workdir):
+    out = run(workdir, f"01-Data/{ML5}.txt", 0, 0, 1, 1, 10, 0, 0, 0, 0, 0, "03-Models/x", "MP")
+    assert '"nUsers": 6040, "nItems": 2848, "nClicks": 30175' in out
+    assert "num_pos_events :18097" in out
+    # the reference prints exactly these two lines for this command (paper Table 4, Pop / ML-5)
+    assert "#Users = 6039, VALID: AUC = 0.739072, MRR = 0.019851, HR@50 = 0.131148" in out
+    assert "#Users = 6039, TEST:  AUC = 0.735201, MRR = 0.018224, HR@50 = 0.126511" in out
+    out2 = run(workdir, f"01-Data/{ML5}z.txt", 0, 0, 1, 1, 10, 0, 0, 0, 0, 0, "03-Models/x", "MP")
+    assert "TEST:  AUC = 0.735201" in out2
+
+
+@pytest.mark.gpu
+def test_bprmf_run_and_saved_model(workdir):
+    out = run(workdir, f"01-Data/{ML5}.txt", 0, 0, 1, 1, 10, 0.01, 0.01, 0, 0, 100, "03-Models/m", "BPRMF")
+    assert "<<< BPR-MF__K_10_lambda_0.010000_biasReg_0.010000 >>>" in out
+    assert len(re.findall(r"^Iter: \d+, took ", out, flags=re.M)) == 100
+    assert len(re.findall(r"^\[Valid AUC = ", out, flags=re.M)) == 2
+    m = re.search(r"Test AUC = ([0-9.]+), Val AUC = ([0-9.]+)", out)
+    auc_test, auc_val = float(m.group(1)), float(m.group(2))
+    assert 0.68 < auc_test < 0.76
+    path = workdir / "03-Models" / "m__BPR-MF__K_10_lambda_0.010000_biasReg_0.010000.txt"
+    W = parse_saved(path)
+    assert len(W) == 91728
+    # the saved file, scored by the CPU oracle, reproduces what the CLI printed (6-decimal text)
+    g, model, co, ci, labels = fixture_case("BPRMF", "ml5")
+    _, counts = make_oracle(g, model, co, ci, labels).eval(W)
+    mm = orc.metrics(counts)
+    assert abs(mm[1] - auc_test) < 2e-4 and abs(mm[0] - auc_val) < 2e-4
+
+
+@pytest.mark.gpu
+def test_rebus_run(workdir):
+    out = run(workdir, f"01-Data/{ML5}.txt", 0, 0, 2, 3, 10, 0.01, 0, 0, -0.6, 100, "03-Models/r", "REBUS")
+    assert "ss : 96-FSUB/ML1M-atmost-5_root_fsub_minCount_2_L_3.txt" in out
+    assert " --NW : 31339 -- " in out
+    assert "Validation ..." in out
+    m = re.search(r"Test AUC = ([0-9.]+), Val AUC = ([0-9.]+)", out)
+    assert 0.70 < float(m.group(1)) < 0.82
+    saved = [f for f in os.listdir(workdir / "03-Models") if f.startswith("r__REBUS_K_10_minCount_2_L_3")]
+    assert len(saved) == 1 and len(parse_saved(workdir / "03-Models" / saved[0])) == 31339
+    out = run(workdir, f"01-Data/{ML5}.txt", 0, 0, 7, 7, 10, 0.01, 0, 0, -0.6, 1, "03-Models/r", "REBUS")
+    assert "No substrings found for the dataset" in out
