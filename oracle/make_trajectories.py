@@ -31,17 +31,22 @@ RUNS = [
 ]
 
 
-def run(cfg):
+SEEDS = (0, 1, 2)   # srand() seed of the run; the CLI uses 0 (main.cpp:144)
+
+
+def run(job):
+    cfg, seed = job
     name, K, L, mc, lam, breg, rreg, alpha, n, c = cfg
-    out = os.path.join(WORK, "out", f"{name}_{L}_{mc}")
+    out = os.path.join(WORK, "out", f"{name}_{L}_{mc}_{seed}")
     cmd = [DRIVER, name, "01-Data/ML1M-atmost-5.txt", str(K), str(L), str(mc), repr(lam), repr(breg), repr(rreg), repr(alpha),
            "-", f"traj:{n}:{c}", "0.05", out]
-    r = subprocess.run(cmd, cwd=WORK, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    r = subprocess.run(cmd, cwd=WORK, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
+                       env=dict(os.environ, REF_SEED=str(seed)))
     traj = [[float(x) for x in ln.split()[1:]] for ln in r.stderr.split("\n") if ln.startswith("TRAJ")]
     best = max(traj, key=lambda t: t[1])
-    res = dict(model=name, K=K, L=L, minCount=mc, lam=lam, bias_reg=breg, relation_reg=rreg, alpha=alpha, epochs=n, every=c,
-               best_iter=int(best[0]), best_auc_val=best[1], auc_test_at_best=best[2], hit50_test_at_best=best[4], trajectory=traj)
-    print(name, L, mc, "best", best, flush=True)
+    res = dict(seed=seed, model=name, K=K, L=L, minCount=mc, lam=lam, bias_reg=breg, relation_reg=rreg, alpha=alpha, epochs=n, every=c,
+               best_iter=int(best[0]), best_auc_val=best[1], auc_test_at_best=best[2], hit50_test_at_best=best[4])
+    print(name, L, mc, "seed", seed, "best", best, flush=True)
     return res
 
 
@@ -54,6 +59,6 @@ if __name__ == "__main__":
         if f.startswith("ML1M-atmost-5_"):
             shutil.copy(os.path.join(REF, "96-FSUB", f), os.path.join(WORK, "96-FSUB"))
     with ThreadPoolExecutor(7) as ex:
-        results = list(ex.map(run, RUNS))
+        results = list(ex.map(run, [(cfg, seed) for cfg in RUNS for seed in SEEDS]))
     with open(os.path.join(GOLD, "ml5_trajectories.json"), "w") as f:
-        json.dump(results, f)
+        json.dump(results, f, indent=0)

@@ -189,7 +189,7 @@ int main(int argc, char** argv)
 	double lr = atof(argv[12]);
 	g_out = argv[13];
 
-	srand(0);
+	srand(getenv("REF_SEED") ? atoi(getenv("REF_SEED")) : 0);   // main.cpp:144 uses 0
 	corpus corp;
 	corp.loadData(data_path, 0, 0);
 	{

@@ -64,9 +64,9 @@ void rec_set_error(const std::string& msg);
 int launch_sgd_sequential(const DevModel& m, int precision, const int4* tuples, int64_t n, double lr, hipStream_t st);
 int launch_sgd_hogwild(const DevModel& m, int precision, const int4* tuples, int64_t n, double lr, int atomic,
                        hipStream_t st);
-int launch_apply_global(const DevModel& m, int precision, double lr, int64_t n_tuples, hipStream_t st);
+int launch_apply_global(const DevModel& m, int precision, double lr, int64_t n_tuples, double cap, hipStream_t st);
 int launch_sgd_history(const DevModel& m, int precision, const int4* tuples, int64_t n, double lr, int atomic, hipStream_t st);
-int launch_apply_global_history(const DevModel& m, int precision, double lr, hipStream_t st);
+int launch_apply_global_history(const DevModel& m, int precision, double lr, double cap, hipStream_t st);
 int launch_sampler(const DevModel& m, int4* tuples, int64_t n, int64_t first_step, uint64_t seed, uint64_t epoch,
                    hipStream_t st);
 int launch_convert_in(const double* src, void* dst, int64_t n, int precision, hipStream_t st);

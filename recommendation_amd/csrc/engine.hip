@@ -35,6 +35,7 @@ struct rec_engine {
     // options
     int64_t chunk = 1 << 22;
     int64_t global_window = 1 << 18;
+    int64_t global_cap = 16;    // a folded-in row moves by at most this many steps' worth of learning rate per launch
     int64_t stale_window = 0;   // tuples per launch so that a row rarely receives more than a couple of stale updates (0 = no limit)
     int atomic = 0x1ff;  // bit r: row r of a tuple is scattered with float atomics; bit 8: the biases
     int profile = 0;
@@ -245,6 +246,8 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
         const int64_t w = (int64_t)(2.0 * I / rows);
         e->stale_window = w >= 65536 ? 0 : std::max<int64_t>(16, w);
     }
+    // Fossil's global weights move by lr/10 per step with a small curvature: a larger budget than TransRec's r
+    if (d->model == REC_FOSSIL || d->model == REC_FOSSIL_SIMPLE) e->global_cap = 4096;
     // scatter policy: exact sums for small problems, the hybrid for large ones (see rec_set_option)
     rec_set_option(e, "update_policy", e->steps_per_epoch >= (1 << 22) ? 1 : 0);
     *out = e;
@@ -406,8 +409,8 @@ static int launch_update(rec_engine* e, const int4* tuples, int64_t n, double lr
                          : launch_sgd_hogwild(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic, e->st);
         if (rc) return rc;
         if (global_row) {
-            if ((rc = launch_apply_global(e->dm, e->desc.precision, lr, len, e->st))) return rc;
-            if ((rc = launch_apply_global_history(e->dm, e->desc.precision, lr, e->st))) return rc;
+            if ((rc = launch_apply_global(e->dm, e->desc.precision, lr, len, (double)e->global_cap, e->st))) return rc;
+            if ((rc = launch_apply_global_history(e->dm, e->desc.precision, lr, (double)e->global_cap, e->st))) return rc;
         }
     }
     return 0;
@@ -611,6 +614,7 @@ extern "C" int rec_set_option(rec_engine* e, const char* name, int64_t value)
     else if (s == "atomic") e->atomic = value == 1 ? 0x1ff : (int)value;  // 1 = every row; else a mask: bit r = row r of the tuple, bit 8 = biases
     else if (s == "profile") e->profile = value != 0;
     else if (s == "stale_window") { if (value < 0) { rec_set_error("stale_window must be >= 0"); return -1; } e->stale_window = value; }
+    else if (s == "global_cap") { if (value < 1) { rec_set_error("global_cap must be positive"); return -1; } e->global_cap = value; }
     else if (s == "global_window") { if (value < 1) { rec_set_error("global_window must be positive"); return -1; } e->global_window = value; }
     else if (s == "update_policy") {
         // 0 exact: every row and bias is scattered with float atomics (sums of all contributions);

@@ -347,10 +347,9 @@ int launch_sgd_history(const DevModel& m, int precision, const int4* tuples, int
                                 : dispatch_history<float>(m, tuples, n, lr, atomic, st);
 }
 
-int launch_apply_global_history(const DevModel& m, int precision, double lr, hipStream_t st)
+int launch_apply_global_history(const DevModel& m, int precision, double lr, double cap, hipStream_t st)
 {
     if (!(m.model == REC_FOSSIL || m.model == REC_FOSSIL_SIMPLE)) return 0;
-    const double cap = 16.0;
     if (precision == REC_F64) hipLaunchKernelGGL(apply_global_history_kernel<double>, dim3(1), dim3(64), 0, st, m, lr, cap);
     else hipLaunchKernelGGL(apply_global_history_kernel<float>, dim3(1), dim3(64), 0, st, m, (float)lr, (float)cap);
     HIP_TRY(hipGetLastError());

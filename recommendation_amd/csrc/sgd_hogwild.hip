@@ -448,10 +448,9 @@ int launch_sgd_hogwild(const DevModel& m, int precision, const int4* tuples, int
                                 : dispatch_model<float>(m, tuples, n, lr, atomic, st);
 }
 
-int launch_apply_global(const DevModel& m, int precision, double lr, int64_t n_tuples, hipStream_t st)
+int launch_apply_global(const DevModel& m, int precision, double lr, int64_t n_tuples, double cap, hipStream_t st)
 {
     if (!(m.model == REC_TRANSREC || m.model == REC_TRANSREC_L1)) return 0;
-    const double cap = 16.0;
     int64_t blocks = ((int64_t)m.I + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     if (precision == REC_F64) {

@@ -40,3 +40,35 @@ def train_like_reference(r, precision=F32, seed=0, max_epochs=None):
     m, _, _ = e.eval(want_counts=False)
     e.close()
     return dict(auc_test=m.auc_test, auc_val=m.auc_val, hit50_test=m.hit_test, epochs=it, best_iter=best_iter)
+
+
+def best_of_trajectory(r, precision=F32, seed=0, policy=None, options=None):
+    """Engine counterpart of oracle/make_trajectories.py: r["epochs"] epochs, full evaluation every
+    r["every"] epochs, returns the checkpoint with the best validation AUC."""
+    co, ci = ml5_corpus()
+    seq_off, seq_item, test, val = orc.split(co, ci)
+    I = int(ci.max()) + 1
+    model = r["model"]
+    po = pi = None
+    if model == "REBUS":
+        labels = read_labels(f"ML1M-atmost-5_root_fsub_minCount_{r['minCount']}_L_{r['L']}.txt.gz")
+        lo, li = orc.parse_labels(labels, I)
+        po, pi = ra.build_rebus_paths(I, seq_off, seq_item, val, lo, li)
+    e = ra.Engine(model, I, seq_off, seq_item, test, val, K=r["K"], L=r["L"], lam=r["lam"], bias_reg=r["bias_reg"],
+                  relation_reg=r["relation_reg"], alpha=r["alpha"], precision=precision, path_off=po, path_item=pi)
+    if policy is not None:
+        e.set_option("update_policy", policy)
+    for k, v in (options or {}).items():
+        e.set_option(k, v)
+    e.init_params(seed)
+    best = None
+    traj = []
+    for it in range(1, r["epochs"] + 1):
+        e.sgd_epoch(0.05, e.steps_per_epoch, seed=seed, epoch=it)
+        if it % r["every"] == 0:
+            m, _, _ = e.eval(want_counts=False)
+            traj.append((it, m.auc_val, m.auc_test))
+            if best is None or m.auc_val > best[1]:
+                best = (it, m.auc_val, m.auc_test, m.hit_test)
+    e.close()
+    return dict(best_iter=best[0], best_auc_val=best[1], auc_test_at_best=best[2], hit50_test_at_best=best[3], trajectory=traj)
