@@ -136,8 +136,16 @@ int64_t rec_rebus_build_paths(int32_t n_users, int32_t n_items, const int64_t* s
 int rec_num_tables(const rec_engine* e);
 int rec_table_info(const rec_engine* e, int t, void** dev_ptr, int64_t* rows, int64_t* cols, int* is_user_table);
 
-/* Tuning knobs: "chunk" (tuples per update launch), "atomic" (1 = float atomics, 0 = plain
- * racy read-modify-write), "profile" (1 = time every update / scoring launch with HIP events) */
+/* Tuning knobs (value 0/1 unless noted):
+ *   "update_policy" 0 = float atomics on every row, 1 = hybrid (plain stores for user rows and for the few
+ *                   items drawn most often, atomics elsewhere), 2 = plain racy stores
+ *   "atomic"        the same as a bit mask: bit r = row r of the tuple, bit 8 = biases
+ *   "hot_count"     items with at least this many training occurrences are stored plainly (0 = none)
+ *   "chunk"         tuples sampled per sampler launch
+ *   "stale_window"  tuples per update launch for small catalogs (0 = no limit)
+ *   "global_window" tuples per update launch for models with a row every tuple touches
+ *   "global_cap"    such a row moves by at most this many steps' worth of learning rate per launch
+ *   "profile"       time every update / scoring / sampler launch with HIP events */
 int rec_set_option(rec_engine* e, const char* name, int64_t value);
 
 /* HIP-event statistics gathered while "profile" = 1: which = 0 SGD update kernel, 1 eval scoring

@@ -238,3 +238,32 @@ def test_errors_are_reported_not_thrown():
     with pytest.raises(RuntimeError, match="out of range"):
         e.sgd_replay(0.05, bad, SEQUENTIAL)
     e.close()
+
+
+def _traj_groups():
+    import json
+    import os
+    from tests.golden_util import GOLD
+    rows = json.load(open(os.path.join(GOLD, "ml5_trajectories.json")))
+    groups = {}
+    for r in rows:
+        if r["seed"] == 1:
+            continue  # glibc's srand(1) is the same stream as srand(0)
+        groups.setdefault((r["model"], r["L"], r["minCount"]), []).append(r)
+    return groups
+
+
+@pytest.mark.parametrize("key", sorted(_traj_groups()))
+def test_converged_auc_within_0_005_of_reference(key):
+    """Criterion (c).  Reference side: its own oneiteration + AUC on ML-5 (K=10), best-validation
+    checkpoint of the trajectory, two srand seeds.  Engine side: device sampler + Hogwild update with the
+    same epochs and evaluation cadence, two seeds.  Bound: |mean test AUC difference| <= 0.005."""
+    from tests.converge_util import best_of_trajectory
+    refs = _traj_groups()[key]
+    ref_test = np.mean([r["auc_test_at_best"] for r in refs])
+    ref_val = np.mean([r["best_auc_val"] for r in refs])
+    got = [best_of_trajectory(refs[0], seed=s) for s in (0, 1)]
+    test_auc = np.mean([g["auc_test_at_best"] for g in got])
+    val_auc = np.mean([g["best_auc_val"] for g in got])
+    assert abs(test_auc - ref_test) <= 0.005, (key, test_auc, ref_test)
+    assert abs(val_auc - ref_val) <= 0.005, (key, val_auc, ref_val)
