@@ -206,8 +206,17 @@ def main():
     tuples_per_launch = my_steps * args.steps / max(upd_n, 1)
     avg_ms = upd_ms / max(upd_n, 1)
     achieved = bytes_per_triple * tuples_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # HBM traffic per launch from the committed rocprofv3 --pmc passes of this same command (profiles/README.md);
+    # only quoted when the profiled launch had the same size
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if os.path.exists(pmc_path) and args.model == "BPRMF" and world == 1:
+        for name, e in json.load(open(pmc_path)).items():
+            if name.startswith("sgd_hogwild_kernel") and "hbm_traffic_bytes_per_launch" in e and \
+                    abs(e.get("tuples_per_launch", 0) - tuples_per_launch) < 0.01 * tuples_per_launch:
+                traffic = int(e["hbm_traffic_bytes_per_launch"])
     roofline = {"bound": "hbm", "kernel": "sgd_hogwild_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "bytes_per_triple": bytes_per_triple, "tuples_per_launch": int(tuples_per_launch),
                 "avg_launch_ms": round(avg_ms, 4), "launches": int(upd_n),
                 "sampler_ms_per_launch": round(smp_ms / max(smp_n, 1), 4)}
