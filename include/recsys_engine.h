@@ -118,6 +118,11 @@ int64_t rec_steps_per_epoch(const rec_engine* e);
  * evaluated).  xpos_out (optional): per user x_test, x_val. */
 int rec_eval(rec_engine* e, int topn, rec_metrics* out, int32_t* counts_out, double* xpos_out);
 
+/* The ranking behind HIT@k (src/model.cpp:52-58): for every listed user, the k best-scored items among the
+ * candidates of model::AUC plus the context's positive, for the validation (index 0) and the test (index 1)
+ * context.  items_out / scores_out: [n_users][2][k], best first; -1 / -inf when fewer than k exist. k <= 256. */
+int rec_eval_topk(rec_engine* e, const int32_t* users, int32_t n_users, int32_t k, int32_t* items_out, double* scores_out);
+
 /* Partial sums of rec_eval over this engine's users, for a sum all-reduce across ranks:
  * {sum AUC_val, AUC_test, HIT_val, HIT_test, MRR_val, MRR_test, sum AUC_test^2, n_users} */
 int rec_eval_sums(rec_engine* e, int topn, double sums[8]);

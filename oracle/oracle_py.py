@@ -129,6 +129,13 @@ class Oracle:
         assert rc == 0
         return xpos, counts
 
+    def score_row(self, W, u, is_test):
+        W = np.ascontiguousarray(W if W is not None else np.zeros(1), np.float64)
+        row = np.zeros(self.n_items, np.float64)
+        rc = lib().orc_score_row(C.byref(self.ctx), _p(W), C.c_int(u), C.c_int(is_test), _p(row))
+        assert rc == 0
+        return row
+
     def bprmf_epoch(self, W, lr, n_steps, seed):
         """In place on W (float64, contiguous)."""
         assert W.dtype == np.float64 and W.flags.c_contiguous

@@ -51,6 +51,10 @@ int orc_replay(const orc_ctx* c, double* W, const int32_t* tuples, int64_t n, do
  * and the Fossil / REBUS overrides.  Invalid users get zeros / -1. nthreads <= 0: all cores. */
 int orc_eval(const orc_ctx* c, const double* W, double* xpos, int32_t* counts, int nthreads);
 
+/* The scores model.cpp:36-47 compares for user u in the validation (is_test = 0) or test context:
+ * row[j] for every candidate j and for the context's positive, -inf for the excluded items. */
+int orc_score_row(const orc_ctx* c, const double* W, int u, int is_test, double* row);
+
 /* counts -> AUC_val AUC_test HIT_val HIT_test MRR_val MRR_test var, model.cpp:49-97 */
 void orc_metrics(int32_t n_users, const int32_t* counts, int topn, double* out7);
 

@@ -14,7 +14,7 @@ SEQUENTIAL, HOGWILD = 0, 1
 
 EXPORTS = ["rec_last_error", "rec_create", "rec_destroy", "rec_sync", "rec_nw", "rec_params_upload",
            "rec_params_download", "rec_params_read", "rec_params_init", "rec_snapshot_best", "rec_restore_best", "rec_sgd_replay",
-           "rec_sgd_epoch", "rec_sample_tuples", "rec_steps_per_epoch", "rec_eval", "rec_eval_sums",
+           "rec_sgd_epoch", "rec_sample_tuples", "rec_steps_per_epoch", "rec_eval", "rec_eval_topk", "rec_eval_sums",
            "rec_rebus_build_paths", "rec_num_tables", "rec_table_info", "rec_set_option", "rec_kernel_stats"]
 
 
@@ -170,6 +170,13 @@ class Engine:
         xpos = np.zeros((self.n_users, 2), np.float64) if want_xpos else None
         _check(lib().rec_eval(self.handle, C.c_int(topn), C.byref(m), _p(counts), _p(xpos)))
         return m, counts, xpos
+
+    def eval_topk(self, users, k=50):
+        users = np.ascontiguousarray(users, np.int32)
+        items = np.zeros((len(users), 2, k), np.int32)
+        scores = np.zeros((len(users), 2, k), np.float64)
+        _check(lib().rec_eval_topk(self.handle, _p(users), C.c_int32(len(users)), C.c_int32(k), _p(items), _p(scores)))
+        return items, scores
 
     def eval_sums(self, topn=50):
         s = np.zeros(8, np.float64)

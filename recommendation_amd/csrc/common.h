@@ -79,6 +79,11 @@ int launch_mark_hot(const DevModel& m, uint8_t* hot, int64_t min_count, hipStrea
 int eval_run(const DevModel& m, int precision, int32_t* counts_host, double* xpos_host, hipStream_t st,
              double* score_ms, int64_t* score_launches, bool profile);
 
+// The k best-scored items of the validation and of the test context of every listed user:
+// items_host / scores_host are [n_users][2][k] (context 0 = validation, 1 = test; -1 / -inf past the end).
+int eval_topk(const DevModel& m, int precision, const int32_t* users_host, int n_users, int k, int32_t* items_host,
+              double* scores_host, hipStream_t st);
+
 #ifdef __HIPCC__
 // ---------------------------------------------------------------- device helpers
 __device__ __forceinline__ float rexp(float x) { return expf(x); }

@@ -594,6 +594,19 @@ extern "C" int rec_eval_sums(rec_engine* e, int topn, double sums[8])
     return 0;
 }
 
+extern "C" int rec_eval_topk(rec_engine* e, const int32_t* users, int32_t n_users, int32_t k, int32_t* items_out, double* scores_out)
+{
+    if (!e || !users || !items_out || !scores_out) { rec_set_error("null argument"); return -1; }
+    if (n_users <= 0) return 0;
+    ENG_HIP(hipSetDevice(e->desc.device));
+    ENG_HIP(hipStreamSynchronize(e->st));
+    std::vector<int32_t> test(e->U);
+    ENG_HIP(hipMemcpy(test.data(), e->dm.test_item, sizeof(int32_t) * e->U, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n_users; i++)
+        if (users[i] < 0 || users[i] >= e->U || test[users[i]] < 0) { rec_set_error("user " + std::to_string(users[i]) + " has no validation / test item"); return -1; }
+    return eval_topk(e->dm, e->desc.precision, users, n_users, k, items_out, scores_out, e->st);
+}
+
 extern "C" int rec_num_tables(const rec_engine* e) { return e ? (int)e->tables.size() : -1; }
 
 extern "C" int rec_table_info(const rec_engine* e, int t, void** dev_ptr, int64_t* rows, int64_t* cols, int* is_user_table)

@@ -28,6 +28,9 @@ struct EvalDev {
     double* bconst;            // [I]
     int32_t* counts;           // [U][3]
     double* xpos;              // [U][2]
+    double* aq;                // [nq_pad] a_q of every query (top-k output only)
+    double* S;                 // [nq_pad][I] relative scores b_j + <q', T_j> (top-k only)
+    int force2;                // 1: one query per (user, context) even for models whose two contexts share q
 };
 
 #define E REC_MAX_EPL
@@ -51,6 +54,7 @@ __global__ void __launch_bounds__(256) build_queries_kernel(DevModel m, EvalDev 
     if (w >= ev.nq) return;
     const int u = m.eval_users[w / ev.nctx];
     const int ctx = ev.nctx == 2 ? (w & 1) : 0;     // 0 = validation, 1 = test
+    const bool shared_q = m.model == REC_BPRMF || m.model == REC_MP;
     const int64_t so = m.seq_off[u]; const int n = (int)(m.seq_off[u + 1] - so);
     const int32_t* seq = m.seq_item + so;
     const int val = m.val_item[u], test = m.test_item[u];
@@ -227,7 +231,9 @@ __global__ void __launch_bounds__(256) build_queries_kernel(DevModel m, EvalDev 
     }
     default: break;
     }
+    if (shared_q && ev.nctx == 2 && ctx == 1) xa = xb;
     if (lane == 0) {
+        if (ev.aq) ev.aq[w] = aq;
         ev.thr[w] = xa - aq;
         if (ev.nctx == 1) {
             ev.thr2[w] = xb - aq;
@@ -291,7 +297,7 @@ template <int KQ> struct TileShape {
     static constexpr int MT = KQ <= 32 ? 4 : KQ <= 64 ? 2 : 1;
 };
 
-template <class T, int KQ, bool TWO>
+template <class T, int KQ, bool TWO, bool STORE>
 __global__ void __launch_bounds__(256) score_count_kernel(EvalDev ev, const T* __restrict__ seg0, const T* __restrict__ seg1,
                                                           const int32_t* __restrict__ qtest, const int32_t* __restrict__ qval, int I)
 {
@@ -366,12 +372,14 @@ __global__ void __launch_bounds__(256) score_count_kernel(EvalDev ev, const T* _
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const double s = acc[mt][r] + bj;
+                    if (STORE) { if (live) ev.S[(qbase + mt * 16 + quad + 4 * r) * (int64_t)I + j] = s; continue; }
                     const bool ok = live && j != ex1[mt][r] && j != ex2[mt][r];
                     cnt[mt][r] += (ok && thr[mt][r] > s) ? 1 : 0;
                     if (TWO) cnt2[mt][r] += (ok && thr2[mt][r] > s) ? 1 : 0;
                 }
         }
     }
+    if (STORE) return;
     // the 16 lanes that share a quad hold partial counts of the same 4 rows
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
@@ -392,7 +400,7 @@ __global__ void __launch_bounds__(256) score_count_kernel(EvalDev ev, const T* _
 // queries for the whole item sweep; items are staged through LDS in tiles of 64 (odd row stride:
 // conflict-free when the 64 lanes of a wavefront read 64 different items), thread (item jj, query
 // group qg) accumulates QT/4 distances per tile.
-template <class T, int QT>
+template <class T, int QT, bool STORE>
 __global__ void __launch_bounds__(256) score_count_l1_kernel(EvalDev ev, const T* __restrict__ H, const int32_t* __restrict__ qtest,
                                                              const int32_t* __restrict__ qval, int I, int K)
 {
@@ -428,9 +436,13 @@ __global__ void __launch_bounds__(256) score_count_l1_kernel(EvalDev ev, const T
         if (j < I) {
             const double bj = ev.bconst[j];
 #pragma unroll
-            for (int a = 0; a < QT / 4; a++) cnt[a] += (j != ex1[a] && j != ex2[a] && thr[a] > -(bj + acc[a])) ? 1 : 0;
+            for (int a = 0; a < QT / 4; a++) {
+                if (STORE) ev.S[(qbase + qg + 4 * a) * (int64_t)I + j] = -(bj + acc[a]);
+                else cnt[a] += (j != ex1[a] && j != ex2[a] && thr[a] > -(bj + acc[a])) ? 1 : 0;
+            }
         }
     }
+    if (STORE) return;
 #pragma unroll
     for (int a = 0; a < QT / 4; a++) {
         int c = cnt[a];
@@ -503,7 +515,7 @@ __global__ void query_items_kernel(DevModel m, EvalDev ev, int32_t* qtest, int32
     qtest[i] = t; qval[i] = v;
 }
 
-template <class T, bool TWO>
+template <class T, bool TWO, bool STORE>
 static int launch_score(const EvalDev& ev, const DevModel& m, const int32_t* qtest, const int32_t* qval, hipStream_t st)
 {
     const T* s0 = ev.seg0 >= 0 ? (const T*)m.tab[ev.seg0] : nullptr;
@@ -511,7 +523,7 @@ static int launch_score(const EvalDev& ev, const DevModel& m, const int32_t* qte
 #define SCORE_CASE(KQv)                                                                                         \
     case KQv: {                                                                                                 \
         const unsigned blocks = (unsigned)(ev.nq_pad / (4 * TileShape<KQv>::MT * 16));                          \
-        hipLaunchKernelGGL((score_count_kernel<T, KQv, TWO>), dim3(blocks), dim3(256), 0, st, ev, s0, s1, qtest, qval, m.I); \
+        hipLaunchKernelGGL((score_count_kernel<T, KQv, TWO, STORE>), dim3(blocks), dim3(256), 0, st, ev, s0, s1, qtest, qval, m.I); \
         break;                                                                                                  \
     }
     switch (ev.KQ) {
@@ -592,11 +604,11 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
     int rc = 0;
     if (l1) {
         const size_t lds_bytes = sizeof(double) * ((size_t)64 * (m.K | 1) + (size_t)L1_QT * m.K);
-        hipLaunchKernelGGL((score_count_l1_kernel<T, L1_QT>), dim3((unsigned)(ev.nq_pad / L1_QT)), dim3(256), lds_bytes, st, ev,
+        hipLaunchKernelGGL((score_count_l1_kernel<T, L1_QT, false>), dim3((unsigned)(ev.nq_pad / L1_QT)), dim3(256), lds_bytes, st, ev,
                            (const T*)m.tab[TR_H], qtest, qval, I, m.K);
         if (hipGetLastError() != hipSuccess) { rec_set_error("launch of the L1 scoring kernel failed"); rc = -2; }
     } else {
-        rc = ev.nctx == 1 ? launch_score<T, true>(ev, m, qtest, qval, st) : launch_score<T, false>(ev, m, qtest, qval, st);
+        rc = ev.nctx == 1 ? launch_score<T, true, false>(ev, m, qtest, qval, st) : launch_score<T, false, false>(ev, m, qtest, qval, st);
     }
     if (rc) { release(); return rc; }
     if (profile) EV_TRY(hipEventRecord(e1, st));
@@ -613,6 +625,184 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
     release();
 #undef EV_TRY
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Top-k lists.  The relative scores of a batch of queries are materialised ([rows][I] f64 in HBM),
+// clicked / held-out items are masked, the context's positive enters with the score the reference
+// formula gives it, and one block per row selects the k largest by an 8-pass radix select on
+// order-preserving 64-bit keys, then orders them (score descending, item id ascending on ties).
+__device__ __forceinline__ uint64_t order_key(double x)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+__global__ void __launch_bounds__(256) topk_mask_kernel(DevModel m, EvalDev ev)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (w >= ev.nq) return;
+    const int u = m.eval_users[w >> 1]; const int ctx = w & 1;
+    double* row = ev.S + (int64_t)w * m.I;
+    const int32_t* clk = m.clk_item + m.clk_off[u]; const int nc = (int)(m.clk_off[u + 1] - m.clk_off[u]);
+    // every address is written by exactly one lane: the positive is skipped here and set by lane 0
+    const int val = m.val_item[u], test = m.test_item[u];
+    const int pos = ctx ? test : val, other = ctx ? val : test;
+    for (int i = lane; i < nc; i += 64) { const int j = clk[i]; if (j != pos && j != other) row[j] = -INFINITY; }
+    if (lane == 0) { if (other != pos) row[other] = -INFINITY; row[pos] = ev.thr[w]; }
+}
+
+__global__ void __launch_bounds__(256) topk_select_kernel(EvalDev ev, int I, int k, int32_t* __restrict__ items_out, double* __restrict__ scores_out)
+{
+    __shared__ unsigned hist[256];
+    __shared__ uint64_t s_prefix; __shared__ int s_need;
+    __shared__ int s_gt, s_eq, s_wave[4];
+    __shared__ double sel_s[256]; __shared__ int sel_i[256];
+    const int tid = threadIdx.x, row = blockIdx.x;
+    const double* S = ev.S + (int64_t)row * I;
+    if (tid == 0) { s_prefix = 0; s_need = k; }
+    __syncthreads();
+    // radix select: after pass p the top 8(p+1) bits of the k-th largest key are known
+    for (int pass = 0; pass < 8; pass++) {
+        const int shift = 56 - 8 * pass;
+        hist[tid] = 0;
+        __syncthreads();
+        const uint64_t prefix = s_prefix; const uint64_t mask = pass == 0 ? 0 : (~0ull << (shift + 8));
+        for (int j = tid; j < I; j += 256) {
+            const uint64_t key = order_key(S[j]);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int need = s_need, d = 255;
+            for (; d > 0; d--) { if ((int)hist[d] >= need) break; need -= (int)hist[d]; }
+            s_prefix = prefix | ((uint64_t)d << shift); s_need = need;
+        }
+        __syncthreads();
+    }
+    const uint64_t T = s_prefix; const int quota_eq = s_need;   // keys > T are all taken, the first quota_eq keys == T by item id
+    if (tid == 0) { s_gt = 0; s_eq = 0; }
+    for (int i = tid; i < 256; i += 256) { sel_s[i] = -INFINITY; sel_i[i] = -1; }
+    __syncthreads();
+    const int n_gt = k - quota_eq;
+    for (int j0 = 0; j0 < I; j0 += 256) {
+        const int j = j0 + tid;
+        const double sc = j < I ? S[j] : -INFINITY;
+        const uint64_t key = order_key(sc);
+        const bool gt = j < I && key > T, eq = j < I && key == T;
+        if (gt) { const int p = atomicAdd(&s_gt, 1); sel_s[p] = sc; sel_i[p] = j; }
+        // ordered compaction of the ties
+        const unsigned long long bal = __ballot(eq);
+        const int wv = tid >> 6, ln = tid & 63;
+        if (ln == 0) s_wave[wv] = __popcll(bal);
+        __syncthreads();
+        int before = __popcll(bal & ((1ull << ln) - 1));
+        for (int q = 0; q < wv; q++) before += s_wave[q];
+        const int base = s_eq;
+        if (eq && base + before < quota_eq) { sel_s[n_gt + base + before] = sc; sel_i[n_gt + base + before] = j; }
+        __syncthreads();
+        if (tid == 0) s_eq = base + s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    // order the k selected entries
+    if (tid < k) {
+        const double si = sel_s[tid]; const int ii = sel_i[tid];
+        int rank = 0;
+        for (int q = 0; q < k; q++) rank += (sel_s[q] > si || (sel_s[q] == si && (sel_i[q] < ii || (sel_i[q] == ii && q < tid)))) ? 1 : 0;
+        const bool real = si > -INFINITY;
+        items_out[(int64_t)row * k + rank] = real ? ii : -1;
+        scores_out[(int64_t)row * k + rank] = real ? si + ev.aq[row] : -INFINITY;
+    }
+}
+
+template <class T>
+static int topk_impl(const DevModel& m0, const int32_t* users_host, int n_users, int k, int32_t* items_host, double* scores_host,
+                     hipStream_t st)
+{
+    if (k < 1 || k > 256) { rec_set_error("k must be in 1..256"); return -1; }
+    DevModel m = m0;
+    const int I = m.I;
+    EvalDev ev = {};
+    ev.nctx = 2; ev.force2 = 1;
+    ev.seg0 = ev.seg1 = -1; ev.K1 = ev.K2 = 0;
+    switch (m.model) {
+    case REC_MP: break;
+    case REC_BPRMF: ev.seg0 = BPRMF_GI; ev.K1 = m.K; break;
+    case REC_MC: ev.seg0 = MC_ETA; ev.K1 = m.K; break;
+    case REC_FPMC: ev.seg0 = FPMC_GI; ev.K1 = m.K; ev.seg1 = FPMC_ETA; ev.K2 = m.KK; break;
+    case REC_PRME: ev.seg0 = PRME_GI; ev.K1 = m.K; ev.seg1 = PRME_ETA; ev.K2 = m.KK; break;
+    case REC_HRM_AVG: case REC_HRM_MAX: ev.seg0 = HRM_V; ev.K1 = m.K; break;
+    case REC_TRANSREC: case REC_TRANSREC_L1: ev.seg0 = TR_H; ev.K1 = m.K; break;
+    case REC_FOSSIL_SIMPLE: ev.seg0 = FS_V; ev.K1 = m.K; break;
+    case REC_FOSSIL: ev.seg0 = FO_V; ev.K1 = m.K; break;
+    case REC_REBUS: ev.seg0 = RB_P; ev.K1 = m.K; break;
+    default: rec_set_error("top-k is not available for this model"); return -1;
+    }
+    const int kw = ev.K1 + ev.K2;
+    if (kw > 256) { rec_set_error("query width above 256 is not supported"); return -1; }
+    ev.KQ = kw <= 16 ? 16 : kw <= 32 ? 32 : kw <= 64 ? 64 : kw <= 128 ? 128 : 256;
+    const bool l1 = m.model == REC_TRANSREC_L1;
+    constexpr int L1_QT = 32;
+    const int mt = ev.KQ <= 32 ? 4 : ev.KQ <= 64 ? 2 : 1;
+    const int qblock = l1 ? L1_QT : 4 * mt * 16;
+    // rows of one batch: at most 2 GiB of scores
+    int batch_users = (int)std::max<int64_t>(1, std::min<int64_t>(4096, ((int64_t)1 << 31) / ((int64_t)I * 8) / 2));
+    std::vector<void*> owned;
+    auto alloc = [&](void** p, size_t bytes) -> hipError_t { hipError_t e = hipMalloc(p, bytes ? bytes : 8); if (e == hipSuccess) owned.push_back(*p); return e; };
+    auto release = [&]() { for (void* p : owned) (void)hipFree(p); };
+#define TK_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { rec_set_error(std::string(#expr) + ": " + hipGetErrorString(_e)); release(); return -2; } } while (0)
+    const int max_rows = ((2 * batch_users + qblock - 1) / qblock) * qblock;
+    int32_t *d_users = nullptr, *qtest = nullptr, *qval = nullptr, *d_items = nullptr; double* d_scores = nullptr;
+    TK_TRY(alloc((void**)&d_users, sizeof(int32_t) * batch_users));
+    TK_TRY(alloc((void**)&ev.Q, sizeof(double) * (size_t)max_rows * ev.KQ));
+    TK_TRY(alloc((void**)&ev.thr, sizeof(double) * max_rows));
+    TK_TRY(alloc((void**)&ev.thr2, sizeof(double) * max_rows));
+    TK_TRY(alloc((void**)&ev.aq, sizeof(double) * max_rows));
+    TK_TRY(alloc((void**)&ev.cnt, sizeof(int32_t) * max_rows));
+    TK_TRY(alloc((void**)&ev.bconst, sizeof(double) * I));
+    TK_TRY(alloc((void**)&ev.xpos, sizeof(double) * (size_t)m.U * 2));
+    TK_TRY(alloc((void**)&ev.S, sizeof(double) * (size_t)max_rows * I));
+    TK_TRY(alloc((void**)&qtest, sizeof(int32_t) * max_rows));
+    TK_TRY(alloc((void**)&qval, sizeof(int32_t) * max_rows));
+    TK_TRY(alloc((void**)&d_items, sizeof(int32_t) * (size_t)max_rows * k));
+    TK_TRY(alloc((void**)&d_scores, sizeof(double) * (size_t)max_rows * k));
+    ev.cnt2 = ev.cnt; ev.counts = nullptr;
+    hipLaunchKernelGGL(item_consts_kernel<T>, dim3(blocks_for_waves(I)), dim3(256), 0, st, m, ev);
+    for (int u0 = 0; u0 < n_users; u0 += batch_users) {
+        const int nu = std::min(batch_users, n_users - u0);
+        TK_TRY(hipMemcpyAsync(d_users, users_host + u0, sizeof(int32_t) * nu, hipMemcpyHostToDevice, st));
+        m.eval_users = d_users; m.n_eval = nu;
+        ev.nq = 2 * nu; ev.nq_pad = ((ev.nq + qblock - 1) / qblock) * qblock;
+        TK_TRY(hipMemsetAsync(ev.Q, 0, sizeof(double) * (size_t)ev.nq_pad * ev.KQ, st));
+        hipLaunchKernelGGL(query_items_kernel, dim3((ev.nq_pad + 255) / 256), dim3(256), 0, st, m, ev, qtest, qval);
+        hipLaunchKernelGGL(build_queries_kernel<T>, dim3(blocks_for_waves(ev.nq)), dim3(256), 0, st, m, ev);
+        int rc = 0;
+        if (l1) {
+            const size_t lds_bytes = sizeof(double) * ((size_t)64 * (m.K | 1) + (size_t)L1_QT * m.K);
+            hipLaunchKernelGGL((score_count_l1_kernel<T, L1_QT, true>), dim3((unsigned)(ev.nq_pad / L1_QT)), dim3(256), lds_bytes, st, ev,
+                               (const T*)m.tab[TR_H], qtest, qval, I, m.K);
+        } else {
+            rc = launch_score<T, false, true>(ev, m, qtest, qval, st);
+        }
+        if (rc) { release(); return rc; }
+        hipLaunchKernelGGL(topk_mask_kernel, dim3(blocks_for_waves(ev.nq)), dim3(256), 0, st, m, ev);
+        hipLaunchKernelGGL(topk_select_kernel, dim3(ev.nq), dim3(256), 0, st, ev, I, k, d_items, d_scores);
+        TK_TRY(hipGetLastError());
+        TK_TRY(hipMemcpyAsync(items_host + (size_t)u0 * 2 * k, d_items, sizeof(int32_t) * (size_t)ev.nq * k, hipMemcpyDeviceToHost, st));
+        TK_TRY(hipMemcpyAsync(scores_host + (size_t)u0 * 2 * k, d_scores, sizeof(double) * (size_t)ev.nq * k, hipMemcpyDeviceToHost, st));
+        TK_TRY(hipStreamSynchronize(st));
+    }
+    release();
+#undef TK_TRY
+    return 0;
+}
+
+int eval_topk(const DevModel& m, int precision, const int32_t* users_host, int n_users, int k, int32_t* items_host,
+              double* scores_host, hipStream_t st)
+{
+    return precision == REC_F64 ? topk_impl<double>(m, users_host, n_users, k, items_host, scores_host, st)
+                                : topk_impl<float>(m, users_host, n_users, k, items_host, scores_host, st);
 }
 
 int eval_run(const DevModel& m, int precision, int32_t* counts_host, double* xpos_host, hipStream_t st, double* score_ms,

@@ -73,6 +73,75 @@ def test_eval_saved_model_matches_reference(tag):
     e.close()
 
 
+def _check_topk(row, items, scores, k):
+    """Same list as the oracle's up to permutations among (near-)equal scores."""
+    order = np.lexsort((np.arange(len(row)), -row))[:k]
+    n_real = int((row[order] > -np.inf).sum())
+    assert (items[:n_real] >= 0).all() and (items[n_real:] == -1).all()
+    got = items[:n_real]
+    assert len(set(got.tolist())) == n_real
+    tol = 1e-9 * max(1.0, float(np.abs(row[order[:n_real]]).max()))
+    assert np.abs(row[got] - scores[:n_real]).max() <= tol          # the score reported is the item's score
+    assert (np.diff(scores[:n_real]) <= 0).all()                      # best first
+    kth = row[order[n_real - 1]]
+    must = np.nonzero(row > kth + tol)[0]
+    assert set(must.tolist()) <= set(got.tolist())
+    assert (row[got] >= kth - tol).all()
+    return np.array_equal(got, order[:n_real])
+
+
+@pytest.mark.parametrize("tag", ["MP"] + ML5_TAGS)
+def test_top50_lists_of_saved_model_match_oracle(tag):
+    """Criterion (b), second half: the 50 best-ranked items per user and context are the oracle's,
+    modulo ties."""
+    g, model, co, ci, labels = fixture_case(tag, "ml5")
+    W = g["W_micro"].astype(np.float64) / 1e6 if "W_micro" in g else None
+    e = make_engine(g, model, co, ci, labels, F64)
+    if W is not None:
+        e.upload(W)
+    o = make_oracle(g, model, co, ci, labels)
+    valid = np.nonzero(np.asarray(g["counts"])[:, 2] >= 0)[0]
+    users = valid[:: max(1, len(valid) // 24)][:24].astype(np.int32)
+    items, scores = e.eval_topk(users, 50)
+    _, counts, _ = e.eval()
+    exact = 0
+    for a, u in enumerate(users):
+        for ctx in (0, 1):
+            row = o.score_row(W, int(u), ctx)
+            exact += _check_topk(row, items[a, ctx], scores[a, ctx], 50)
+            # HIT@50 of model.cpp:52-58 is membership of the positive in this list
+            pos = int(o.val_item[u] if ctx == 0 else o.test_item[u])
+            if model != "MP":
+                rank = counts[u, 2] - counts[u, ctx]
+                assert (pos in items[a, ctx].tolist()) == (rank < 50)
+    if model != "MP":   # MostPopular scores are integers: ties everywhere
+        assert exact >= 0.9 * 2 * len(users)
+    e.close()
+
+
+@pytest.mark.parametrize("model", EVAL_MODELS)
+def test_topk_toy_all_models_and_short_lists(model):
+    g, model, co, ci, labels = fixture_case(model, "toy")
+    e = make_engine(g, model, co, ci, labels, F64)
+    W = g["W1"] if model != "MP" else None
+    if W is not None:
+        e.upload(W)
+    o = make_oracle(g, model, co, ci, labels)
+    users = np.nonzero(np.asarray(g["counts"])[:, 2] >= 0)[0][:12].astype(np.int32)
+    for k in (1, 7, 256):   # 256 exceeds the toy catalog's candidates for some users
+        items, scores = e.eval_topk(users, k)
+        for a, u in enumerate(users):
+            for ctx in (0, 1):
+                _check_topk(o.score_row(W, int(u), ctx), items[a, ctx], scores[a, ctx], k)
+    with pytest.raises(RuntimeError):
+        e.eval_topk(users, 257)
+    bad = np.nonzero(np.asarray(g["counts"])[:, 2] < 0)[0]
+    if len(bad):
+        with pytest.raises(RuntimeError):
+            e.eval_topk(bad[:1].astype(np.int32), 5)
+    e.close()
+
+
 @pytest.mark.parametrize("tag", ["BPRMF", "TransRec", "REBUS_mc2_L3"])
 def test_eval_f32_storage_matches_oracle_on_same_values(tag):
     """f32 tables are scored in f64 after an exact widening, so the oracle fed the rounded values must agree."""
