@@ -93,8 +93,10 @@ def main():
     ap.add_argument("--k", type=int, default=64)
     ap.add_argument("--model", default="BPRMF")
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--group", type=int, default=-1, help="group_by_item: 0 off, 1 run-combining kernel only, 2 event-major sampling (chunks grouped by positive item); -1 = engine default")
     ap.add_argument("--policy", type=int, default=-1, help="update_policy: 0 exact atomics, 1 hybrid, 2 plain stores; -1 = engine default")
-    ap.add_argument("--chunk", type=int, default=1 << 24)
+    ap.add_argument("--chunk", type=int, default=1 << 27)
+    ap.add_argument("--overlap", type=int, default=0)
     ap.add_argument("--eval-users", type=int, default=0, help="evaluate only the first n users of each shard (0 = all)")
     ap.add_argument("--cpu-steps", type=int, default=12_000_000, help="tuples of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-eval", action="store_true")
@@ -151,7 +153,11 @@ def main():
     if args.policy >= 0:
         eng.set_option("update_policy", args.policy)
     policy = args.policy if args.policy >= 0 else (1 if eng.steps_per_epoch >= (1 << 22) else 0)
+    if args.group >= 0:
+        eng.set_option("group_by_item", args.group)
+    grouped = (args.group if args.group >= 0 else 0) == 2 and args.model in ("BPRMF", "MC", "FPMC", "PRME", "HRM_avg", "HRM_max")
     eng.set_option("chunk", args.chunk)
+    eng.set_option("overlap", args.overlap)
     eng.set_option("profile", 1)
     steps_per_epoch = eng.steps_per_epoch
     my_steps = steps_per_epoch // world
@@ -196,7 +202,7 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         all_reduce(tt, dist.ReduceOp.MAX)
         dt = float(tt.item())
-    total_triples = my_steps * world * args.steps
+    total_triples = my_steps * world * args.steps   # expected; the event-major sampler draws Poisson(this) tuples
     value = total_triples / dt
 
     # algorithmic bytes per triple: distinct rows read once + written once (model-specific)
@@ -212,14 +218,15 @@ def main():
     pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
     if os.path.exists(pmc_path) and args.model == "BPRMF" and world == 1:
         for name, e in json.load(open(pmc_path)).items():
-            if name.startswith("sgd_hogwild_kernel") and "hbm_traffic_bytes_per_launch" in e and \
+            if name.startswith("sgd_runs_kernel" if grouped else "sgd_hogwild_kernel") and "hbm_traffic_bytes_per_launch" in e and \
                     abs(e.get("tuples_per_launch", 0) - tuples_per_launch) < 0.01 * tuples_per_launch:
                 traffic = int(e["hbm_traffic_bytes_per_launch"])
-    roofline = {"bound": "hbm", "kernel": "sgd_hogwild_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+    roofline = {"bound": "hbm", "kernel": "sgd_runs_kernel" if grouped else "sgd_hogwild_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "bytes_per_triple": bytes_per_triple, "tuples_per_launch": int(tuples_per_launch),
                 "avg_launch_ms": round(avg_ms, 4), "launches": int(upd_n),
-                "sampler_ms_per_launch": round(smp_ms / max(smp_n, 1), 4)}
+                "sampler_ms_per_launch": round(smp_ms / max(smp_n, 1), 4),
+                "tuples_drawn_over_expected": round(eng.tuples_drawn / max(1, my_steps * (args.steps + args.warmup)), 6)}
 
     out = {"metric": "bpr_sgd_triples_per_sec", "value": round(value, 1), "unit": "triples/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -227,7 +234,7 @@ def main():
            "data": "synthetic",
            "config": {"workload": f"{args.model} K={K} oneiteration (BPR-SGD epoch) on synthetic {U} users x {I} items x "
                                   f"{n_clicks} interactions", "triples_per_step": my_steps * world,
-                      "update": ["float atomics on every row", "float atomics on item rows and biases (plain stores for user rows and for items holding >= 1/1024 of the positives)", "plain stores"][policy], "parallelism": f"user-sharded x{world}"},
+                      "update": ["float atomics on every row", "float atomics on item rows (plain stores for user rows, biases and items holding >= 1/1024 of the positives)", "plain stores"][policy] + (", chunks drawn by event and grouped by positive item, one atomic row per run" if grouped else ""), "parallelism": f"user-sharded x{world}"},
            "roofline": roofline}
 
     # ---------------- evaluation: users/s over the full catalog

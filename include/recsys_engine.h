@@ -107,6 +107,15 @@ int rec_sgd_replay(rec_engine* e, double lr, const int32_t* tuples, int64_t n, i
  * the device by a counter-based generator keyed by (seed, epoch, step), applied Hogwild-style */
 int rec_sgd_epoch(rec_engine* e, double lr, int64_t n_steps, uint64_t seed, uint64_t epoch);
 
+/* Large problems ("group_by_item" = 2, the default with the hybrid update policy) draw a chunk by event instead
+ * of by tuple: every (user, position) the samplers above can pick yields Poisson(n * P(position)) tuples.  The
+ * tuples of a chunk are the same i.i.d. draws, grouped by positive item, and their number is Poisson(n) instead
+ * of exactly n.  rec_tuples_drawn: the number of tuples rec_sgd_epoch has applied since rec_create. */
+int64_t rec_tuples_drawn(const rec_engine* e);
+
+/* the event-major sampler alone: up to cap tuples (4 x int32) to host memory, *n_out of them (mean n_expected) */
+int rec_sample_events(rec_engine* e, int64_t n_expected, uint64_t seed, uint64_t epoch, int64_t cap, int32_t* tuples_out, int64_t* n_out);
+
 /* the sampler alone (tests, tuple capture): writes n tuples (4 x int32) to host memory */
 int rec_sample_tuples(rec_engine* e, int64_t n, uint64_t seed, uint64_t epoch, int32_t* tuples_out);
 
@@ -142,11 +151,15 @@ int rec_num_tables(const rec_engine* e);
 int rec_table_info(const rec_engine* e, int t, void** dev_ptr, int64_t* rows, int64_t* cols, int* is_user_table);
 
 /* Tuning knobs (value 0/1 unless noted):
- *   "update_policy" 0 = float atomics on every row, 1 = hybrid (plain stores for user rows and for the few
- *                   items drawn most often, atomics elsewhere), 2 = plain racy stores
+ *   "update_policy" 0 = float atomics on every row, 1 = hybrid (plain stores for user rows, biases and the few
+ *                   items drawn most often, atomics on the other item rows), 2 = plain racy stores
  *   "atomic"        the same as a bit mask: bit r = row r of the tuple, bit 8 = biases
  *   "hot_count"     items with at least this many training occurrences are stored plainly (0 = none)
- *   "chunk"         tuples sampled per sampler launch
+ *   "group_by_item" 0 = off, 1 = the update kernel combines runs of equal positive items into one scatter,
+ *                   2 = 1 + chunks are drawn by event, which groups them by positive item
+ *   "run_segment"   batches one lane group of the run-combining kernel walks (0 = automatic)
+ *   "chunk"         tuples sampled per sampler launch (default 2^26)
+ *   "overlap"       1 = sample chunk c+1 on a second stream while chunk c is applied (default 0: measured slower)
  *   "stale_window"  tuples per update launch for small catalogs (0 = no limit)
  *   "global_window" tuples per update launch for models with a row every tuple touches
  *   "global_cap"    such a row moves by at most this many steps' worth of learning rate per launch

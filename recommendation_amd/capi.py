@@ -14,7 +14,7 @@ SEQUENTIAL, HOGWILD = 0, 1
 
 EXPORTS = ["rec_last_error", "rec_create", "rec_destroy", "rec_sync", "rec_nw", "rec_params_upload",
            "rec_params_download", "rec_params_read", "rec_params_init", "rec_snapshot_best", "rec_restore_best", "rec_sgd_replay",
-           "rec_sgd_epoch", "rec_sample_tuples", "rec_steps_per_epoch", "rec_eval", "rec_eval_topk", "rec_eval_sums",
+           "rec_sgd_epoch", "rec_sample_tuples", "rec_sample_events", "rec_tuples_drawn", "rec_steps_per_epoch", "rec_eval", "rec_eval_topk", "rec_eval_sums",
            "rec_rebus_build_paths", "rec_num_tables", "rec_table_info", "rec_set_option", "rec_kernel_stats"]
 
 
@@ -55,6 +55,8 @@ def lib():
         _lib.rec_nw.argtypes = [C.c_void_p]
         _lib.rec_steps_per_epoch.restype = C.c_int64
         _lib.rec_steps_per_epoch.argtypes = [C.c_void_p]
+        _lib.rec_tuples_drawn.restype = C.c_int64
+        _lib.rec_tuples_drawn.argtypes = [C.c_void_p]
         _lib.rec_rebus_build_paths.restype = C.c_int64
     return _lib
 
@@ -163,6 +165,18 @@ class Engine:
         out = np.zeros((n, 4), np.int32)
         _check(lib().rec_sample_tuples(self.handle, C.c_int64(n), C.c_uint64(seed), C.c_uint64(epoch), _p(out)))
         return out
+
+    def sample_events(self, n_expected, seed, epoch, cap=None):
+        cap = int(cap if cap is not None else n_expected + 8 * n_expected ** 0.5 + 1024)
+        out = np.zeros((cap, 4), np.int32)
+        n = C.c_int64(0)
+        _check(lib().rec_sample_events(self.handle, C.c_int64(n_expected), C.c_uint64(seed), C.c_uint64(epoch), C.c_int64(cap),
+                                       _p(out), C.byref(n)))
+        return out[:n.value]
+
+    @property
+    def tuples_drawn(self):
+        return int(lib().rec_tuples_drawn(self.handle))
 
     def eval(self, topn=50, want_counts=True, want_xpos=False):
         m = Metrics()

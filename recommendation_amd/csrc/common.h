@@ -34,6 +34,10 @@ struct DevModel {
     void* gacc;                         // accumulators for rows every tuple touches (TransRec r, Fossil WT, FossilSimple alpha)
     const int32_t* eval_users;          // users of this engine's shard that have a test item
     int n_eval;
+    const uint32_t* neg_filter;         // [U or I][16] 512-bit membership filter of the set a drawn negative must avoid (clicked items; MC: successors)
+    const int4* ev;                     // [n_ev] sampling events ordered by positive item: (owner, aux, positive, -), see launch_event_sampler
+    const float* ev_w;                  // [n_ev] 1 / (number of events of the owner)
+    int64_t n_ev;
     const int32_t* train_count;         // [I] occurrences of each item in the training sequences (MostPopular)
     const uint8_t* hot;                 // [I+1] 1 = item whose rows are not scattered with atomics (see rec_set_option "hot_count")
 };
@@ -72,6 +76,23 @@ int launch_sampler(const DevModel& m, int4* tuples, int64_t n, int64_t first_ste
 int launch_convert_in(const double* src, void* dst, int64_t n, int precision, hipStream_t st);
 int launch_convert_out(const void* src, double* dst, int64_t n, int precision, hipStream_t st);
 int launch_param_init(const DevModel& m, int precision, uint64_t seed, hipStream_t st);
+// Tuples grouped by positive item and the update kernel that turns each run of equal positives into one
+// scatter (models without a row shared by all tuples and without a read-time projection).
+bool sgd_runs_supported(int model);
+// How long a run of equal positives stays private before it is scattered: `shared` for an item whose run
+// continues in a neighbouring segment, `hot` for an item that fills whole segments (scattered with atomics if
+// hot_atomic, else with plain stores).
+struct RunPolicy { int shared, hot, hot_atomic; };
+// segment: batches walked by one lane group (0 = chosen from n)
+int launch_sgd_runs(const DevModel& m, int precision, const int4* tuples, int64_t n, double lr, int atomic, int64_t segment,
+                    RunPolicy rp, hipStream_t st);
+// Event-major sampling: every sampling event (an owner's position) independently yields Poisson(n_expected *
+// P(event)) tuples, written in event order, i.e. grouped by positive item.  *n_out_dev (device, int64) receives
+// the number of tuples drawn (its mean is n_expected); at most cap are written.  scratch: event_scratch_bytes().
+size_t event_scratch_bytes(int64_t n_ev);
+int launch_event_sampler(const DevModel& m, int4* tuples, int64_t cap, int64_t n_expected, int64_t first_step, uint64_t chunk_no,
+                         uint64_t seed, uint64_t epoch, void* scratch, int64_t* n_out_dev, hipStream_t st);
+
 int launch_mark_hot(const DevModel& m, uint8_t* hot, int64_t min_count, hipStream_t st);
 
 // Full-catalog evaluation of the users in m.eval_users.  counts_host: [U][3] (count_val, count_test,
@@ -122,6 +143,14 @@ __device__ __forceinline__ uint4 philox4x32(uint4 ctr, uint2 key)
 __device__ __forceinline__ uint32_t bounded(uint32_t r, uint32_t n) { return __umulhi(r, n); }
 
 // is `x` in the sorted array a[0..n) ?
+// One-hash 512-bit filter in front of a sorted set: a clear bit proves absence with one load
+__host__ __device__ __forceinline__ uint32_t filter_slot(int32_t item) { return ((uint32_t)item * 2654435761u) >> 23; }
+__device__ __forceinline__ bool filter_may_contain(const uint32_t* __restrict__ f, int owner, int32_t item)
+{
+    const uint32_t h = filter_slot(item);
+    return (f[(int64_t)owner * 16 + (h >> 5)] >> (h & 31)) & 1u;
+}
+
 __device__ __forceinline__ bool sorted_contains(const int32_t* a, int n, int32_t x)
 {
     int lo = 0, hi = n;

@@ -1,5 +1,6 @@
 // C ABI of librecsys_amd.so: engine life cycle, parameter transfer, dispatch to the kernels.
 #include "common.h"
+#include <cmath>
 #include <algorithm>
 #include <math.h>
 #include <string.h>
@@ -18,6 +19,7 @@ struct rec_engine {
     rec_model_desc desc;
     int U = 0, I = 0;
     int64_t E = 0, nw = 0, dev_elems = 0, steps_per_epoch = 0;
+    int64_t tuples_drawn = 0;  // tuples applied by rec_sgd_epoch so far
     int elem_size = 4;
     std::vector<TableDesc> tables;
     DevModel dm;
@@ -27,22 +29,28 @@ struct rec_engine {
     double* stage = nullptr; // f64 staging for upload / download
     int64_t stage_elems = 0;
     int4* tuples = nullptr;  // two tuple buffers of `tuples_cap` each: chunk c+1 is sampled while chunk c is applied
+    void* group_scratch = nullptr;  // block sums of the event-major sampler
+    int64_t* n_drawn_dev = nullptr; // its tuple count
     int64_t tuples_cap = 0;
     hipStream_t st2 = nullptr;                 // sampler stream
     hipEvent_t ev_sampled[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
     bool consumed_valid[2] = {false, false};
     std::vector<void*> owned;
     // options
-    int64_t chunk = 1 << 22;
+    int64_t chunk = 1 << 26;
+    int overlap = 0;     // 1: the sampler of chunk c+1 runs on a second stream next to the update of chunk c
     int64_t global_window = 1 << 18;
     int64_t global_cap = 16;    // a folded-in row moves by at most this many steps' worth of learning rate per launch
     int64_t stale_window = 0;   // tuples per launch so that a row rarely receives more than a couple of stale updates (0 = no limit)
     int atomic = 0x1ff;  // bit r: row r of a tuple is scattered with float atomics; bit 8: the biases
     int profile = 0;
-    // hip-event statistics: 0 update, 1 score, 2 sampler
-    double ms[3] = {0, 0, 0};
-    int64_t launches[3] = {0, 0, 0};
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[3];
+    RunPolicy run_policy = {128, 32, 0};
+    int64_t run_segment = 0;  // batches per lane group in the run-combining kernel (0 = automatic)
+    int group = 0;       // 1: run-combining update kernel on the tuples as they come; 2: also sample by event, which yields chunks grouped by positive item
+    // hip-event statistics: 0 update, 1 score, 2 sampler, 3 unused
+    double ms[4] = {0, 0, 0, 0};
+    int64_t launches[4] = {0, 0, 0, 0};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[4];
 };
 
 static int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -177,6 +185,55 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
             if (ok) elig.push_back(u);
         }
     }
+    // filter in front of the set a negative is tested against (sampler.hip)
+    std::vector<uint32_t> neg_filter;
+    if (d->model == REC_BPRMF || d->model == REC_TRANSREC || d->model == REC_TRANSREC_L1 || d->model == REC_MC) {
+        const bool mc = d->model == REC_MC;
+        const int owners = mc ? I : U;
+        neg_filter.assign((size_t)owners * 16, 0u);
+        for (int o = 0; o < owners; o++) {
+            const int64_t b0 = mc ? sset_off[o] : clk_off[o], b1 = mc ? sset_off[o + 1] : clk_off[o + 1];
+            for (int64_t p = b0; p < b1; p++) {
+                const uint32_t h = filter_slot(mc ? sset_item[p] : clk_item[p]);
+                neg_filter[(size_t)o * 16 + (h >> 5)] |= 1u << (h & 31);
+            }
+        }
+    }
+    // sampling events ordered by positive item (launch_event_sampler): one per (owner, position) the tuple-major
+    // sampler can pick, with the owner's 1/count as weight
+    std::vector<int4> ev; std::vector<float> ev_w;
+    if (sgd_runs_supported(d->model)) {
+        const bool mc = d->model == REC_MC, bpr = d->model == REC_BPRMF;
+        auto n_events = [&](int o) -> int64_t { return mc ? succ_off[o + 1] - succ_off[o] : bpr ? seq_off[o + 1] - seq_off[o] : seq_off[o + 1] - seq_off[o] - 1; };
+        auto event_of = [&](int o, int64_t x) -> int4 {
+            if (mc) return make_int4(o, 0, succ_item[succ_off[o] + x], 0);
+            if (bpr) return make_int4(o, 0, seq_item[seq_off[o] + x], 0);
+            return make_int4(o, seq_item[seq_off[o] + x], seq_item[seq_off[o] + x + 1], 0);
+        };
+        std::vector<int64_t> start(I + 1, 0);
+        int64_t total = 0;
+        for (int o : elig) { const int64_t c = n_events(o); total += c; for (int64_t x = 0; x < c; x++) start[event_of(o, x).z + 1]++; }
+        for (int i = 0; i < I; i++) start[i + 1] += start[i];
+        ev.resize(total); ev_w.resize(total);
+        for (int o : elig) {
+            const int64_t c = n_events(o); const float w = 1.0f / (float)c;
+            for (int64_t x = 0; x < c; x++) { const int4 r = event_of(o, x); const int64_t at = start[r.z]++; ev[at] = r; ev_w[at] = w; }
+        }
+        // The events of one item are kept in random order.  In owner order every popular item would visit the
+        // users in the same sequence, and the lane groups working on different items would reach the same user
+        // at the same moment, launch after launch.
+        uint64_t x64 = 0x2545F4914F6CDD1Dull;
+        auto rnd = [&](uint64_t bound) { x64 ^= x64 << 13; x64 ^= x64 >> 7; x64 ^= x64 << 17; return (x64 >> 11) % bound; };
+        int64_t b0 = 0;
+        for (int i = 0; i < I; i++) {   // start[i] is now the end of item i's events
+            const int64_t b1 = start[i];
+            for (int64_t k = b1 - 1; k > b0; k--) {
+                const int64_t j = b0 + (int64_t)rnd((uint64_t)(k - b0 + 1));
+                std::swap(ev[k], ev[j]); std::swap(ev_w[k], ev_w[j]);
+            }
+            b0 = b1;
+        }
+    }
     for (int u = ub; u < ue; u++) if (test_item[u] >= 0) eval_users.push_back(u);
     for (int u : eval_users)
         if (seq_off[u + 1] - seq_off[u] < 1 || val_item[u] < 0 || val_item[u] >= I || test_item[u] >= I) {
@@ -200,7 +257,7 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
 #define UP(vec, field) if (!rc) rc = upload(e, vec, &m.field)
     UP(seq_off, seq_off); UP(seq_item, seq_item); UP(test_item, test_item); UP(val_item, val_item);
     UP(clk_off, clk_off); UP(clk_item, clk_item); UP(first_occ, first_occ); UP(elig, elig); UP(eval_users, eval_users);
-    UP(train_count, train_count); UP(eta, eta);
+    UP(train_count, train_count); UP(eta, eta); UP(ev, ev); UP(ev_w, ev_w); UP(neg_filter, neg_filter);
     if (d->model == REC_MC) { UP(succ_off, succ_off); UP(succ_item, succ_item); UP(sset_off, sset_off); UP(sset_item, sset_item); }
     if (d->model == REC_REBUS && !rc) {
         const int64_t nctx = E + 2 * (int64_t)U;
@@ -211,7 +268,7 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
         UP(po, path_off); UP(pi, path_item);
     }
 #undef UP
-    m.n_elig = (int)elig.size(); m.n_eval = (int)eval_users.size();
+    m.n_elig = (int)elig.size(); m.n_eval = (int)eval_users.size(); m.n_ev = (int64_t)ev.size();
     auto fail = [&](int code) { rec_destroy(e); return code; };
     if (rc) return fail(rc);
     if (hipStreamCreate(&e->st) != hipSuccess || hipStreamCreate(&e->st2) != hipSuccess) { rec_set_error("hipStreamCreate failed"); return fail(-2); }
@@ -228,6 +285,12 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     if (hipMalloc(&g, 8 * (REC_MAX_K + 2 * REC_MAX_L + 8)) != hipSuccess) { rec_set_error("hipMalloc failed"); return fail(-2); }
     e->owned.push_back(g); (void)hipMemset(g, 0, 8 * (REC_MAX_K + 2 * REC_MAX_L + 8));
     m.gacc = g;
+    if (m.n_ev > 0) {
+        if (hipMalloc(&e->group_scratch, event_scratch_bytes(m.n_ev)) != hipSuccess || hipMalloc((void**)&e->n_drawn_dev, 64) != hipSuccess) {
+            rec_set_error("hipMalloc failed"); return fail(-2);
+        }
+        e->owned.push_back(e->group_scratch); e->owned.push_back(e->n_drawn_dev);
+    }
     void* hot = nullptr;
     if (hipMalloc(&hot, I + 64) != hipSuccess) { rec_set_error("hipMalloc failed"); return fail(-2); }
     e->owned.push_back(hot); (void)hipMemset(hot, 0, I + 64);
@@ -244,7 +307,12 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
         default: break;
         }
         const int64_t w = (int64_t)(2.0 * I / rows);
-        e->stale_window = w >= 65536 ? 0 : std::max<int64_t>(16, w);
+        // tuples a launch has in flight at most: 2048 resident blocks, 256 / (lanes per tuple) groups each, B tuples per group
+        const int kmax = std::max(e->desc.K, e->desc.KK);
+        const int lanes = kmax <= 16 ? 16 : kmax <= 32 ? 32 : 64;
+        const int per_group = kmax > 128 ? 1 : kmax > 64 ? 2 : (d->model == REC_FPMC || d->model == REC_PRME) ? 2 : 4;
+        const int64_t in_flight = 2048LL * (256 / lanes) * per_group;
+        e->stale_window = w >= in_flight ? 0 : std::max<int64_t>(16, w);
     }
     // Fossil's global weights move by lr/10 per step with a small curvature: a larger budget than TransRec's r
     if (d->model == REC_FOSSIL || d->model == REC_FOSSIL_SIMPLE) e->global_cap = 4096;
@@ -284,6 +352,7 @@ extern "C" int rec_sync(rec_engine* e)
 
 extern "C" int64_t rec_nw(const rec_engine* e) { return e ? e->nw : -1; }
 extern "C" int64_t rec_steps_per_epoch(const rec_engine* e) { return e ? e->steps_per_epoch : -1; }
+extern "C" int64_t rec_tuples_drawn(const rec_engine* e) { return e ? e->tuples_drawn : -1; }
 
 static int ensure_stage(rec_engine* e, int64_t elems)
 {
@@ -396,7 +465,7 @@ static int ensure_tuples(rec_engine* e, int64_t n)
 // Hogwild launches over `n` tuples.  Models with a row that every tuple touches (TransRec's r,
 // Fossil's WT, FossilSimple's alpha) keep that row constant during a launch and fold its summed
 // gradient in afterwards, so their launches are kept short (`global_window` tuples).
-static int launch_update(rec_engine* e, const int4* tuples, int64_t n, double lr)
+static int launch_update(rec_engine* e, const int4* tuples, int64_t n, double lr, bool grouped = false)
 {
     const int model = e->desc.model;
     const bool history = model == REC_FOSSIL || model == REC_FOSSIL_SIMPLE || model == REC_REBUS;
@@ -406,6 +475,7 @@ static int launch_update(rec_engine* e, const int4* tuples, int64_t n, double lr
     for (int64_t o = 0; o < n; o += window) {
         const int64_t len = std::min(window, n - o);
         int rc = history ? launch_sgd_history(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic, e->st)
+                 : ((grouped || e->group == 1) && sgd_runs_supported(model)) ? launch_sgd_runs(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic, e->run_segment, e->run_policy, e->st)
                          : launch_sgd_hogwild(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic, e->st);
         if (rc) return rc;
         if (global_row) {
@@ -502,27 +572,61 @@ extern "C" int rec_sgd_epoch(rec_engine* e, double lr, int64_t n_steps, uint64_t
     if (n_steps <= 0) return 0;
     ENG_HIP(hipSetDevice(e->desc.device));
     const int64_t chunk = std::min(e->chunk, n_steps);
-    if (e->tuples_cap < chunk) { if (int rc = ensure_tuples(e, chunk)) return rc; }
+    // event-major chunks have a Poisson-distributed length: room for 8 standard deviations
+    const bool grouped = e->group >= 2 && e->dm.n_ev > 0 && (e->stale_window == 0 || e->stale_window >= chunk);
+    const int64_t cap = grouped ? chunk + 8 * (int64_t)std::sqrt((double)chunk) + 1024 : chunk;
+    if (e->tuples_cap < cap) { if (int rc = ensure_tuples(e, cap)) return rc; }
     hipEvent_t a = nullptr, b = nullptr;
+    // By default the sampler of a chunk runs on the update stream, ahead of its update: sampling chunk c+1 next to
+    // the update of chunk c (option "overlap") was measured slower, both kernels being bound by random memory traffic.
+    hipStream_t ss = e->overlap ? e->st2 : e->st;
     int c = 0;
     for (int64_t o = 0; o < n_steps; o += chunk, c++) {
-        const int64_t len = std::min(chunk, n_steps - o);
-        const int buf = c & 1;
+        int64_t len = std::min(chunk, n_steps - o);
+        const int buf = e->overlap ? (c & 1) : 0;
         int4* tb = e->tuples + (int64_t)buf * e->tuples_cap;
-        // sampler stream: the buffer must have been consumed by the update that last read it
-        if (e->consumed_valid[buf]) ENG_HIP(hipStreamWaitEvent(e->st2, e->ev_consumed[buf], 0));
-        if (e->profile) { ENG_HIP(hipEventCreate(&a)); ENG_HIP(hipEventCreate(&b)); ENG_HIP(hipEventRecord(a, e->st2)); }
-        if (int rc = launch_sampler(e->dm, tb, len, o, seed, epoch, e->st2)) return rc;
-        if (e->profile) { ENG_HIP(hipEventRecord(b, e->st2)); e->pending[2].push_back({a, b}); }
-        ENG_HIP(hipEventRecord(e->ev_sampled[buf], e->st2));
-        // update stream
-        ENG_HIP(hipStreamWaitEvent(e->st, e->ev_sampled[buf], 0));
+        // the buffer must have been consumed by the update that last read it
+        if (e->overlap && e->consumed_valid[buf]) ENG_HIP(hipStreamWaitEvent(ss, e->ev_consumed[buf], 0));
+        if (e->profile) { ENG_HIP(hipEventCreate(&a)); ENG_HIP(hipEventCreate(&b)); ENG_HIP(hipEventRecord(a, ss)); }
+        if (grouped) {
+            if (int rc = launch_event_sampler(e->dm, tb, e->tuples_cap, len, o, (uint64_t)c, seed, epoch, e->group_scratch, e->n_drawn_dev, ss)) return rc;
+        } else {
+            if (int rc = launch_sampler(e->dm, tb, len, o, seed, epoch, ss)) return rc;
+        }
+        if (e->profile) { ENG_HIP(hipEventRecord(b, ss)); e->pending[2].push_back({a, b}); }
+        if (grouped) {
+            // the chunk's length is known once it has been drawn
+            int64_t drawn = 0;
+            ENG_HIP(hipMemcpyAsync(&drawn, e->n_drawn_dev, sizeof drawn, hipMemcpyDeviceToHost, ss));
+            ENG_HIP(hipStreamSynchronize(ss));
+            len = std::min(drawn, e->tuples_cap);
+        }
+        if (e->overlap) {
+            ENG_HIP(hipEventRecord(e->ev_sampled[buf], ss));
+            ENG_HIP(hipStreamWaitEvent(e->st, e->ev_sampled[buf], 0));
+        }
         if (int rc = ev_begin(e, 0, &a, &b)) return rc;
-        if (int rc = launch_update(e, tb, len, lr)) return rc;
+        if (int rc = launch_update(e, tb, len, lr, grouped && e->group == 2)) return rc;
         if (int rc = ev_end(e, 0, a, b)) return rc;
-        ENG_HIP(hipEventRecord(e->ev_consumed[buf], e->st));
-        e->consumed_valid[buf] = true;
+        if (e->overlap) { ENG_HIP(hipEventRecord(e->ev_consumed[buf], e->st)); e->consumed_valid[buf] = true; }
+        e->tuples_drawn += len;
     }
+    return 0;
+}
+
+extern "C" int rec_sample_events(rec_engine* e, int64_t n_expected, uint64_t seed, uint64_t epoch, int64_t cap, int32_t* out, int64_t* n_out)
+{
+    if (!e || !out || !n_out) { rec_set_error("null argument"); return -1; }
+    if (n_expected <= 0 || cap <= 0) { rec_set_error("n_expected and cap must be positive"); return -1; }
+    if (e->dm.n_ev <= 0) { rec_set_error("the event-major sampler is not available for this model"); return -1; }
+    ENG_HIP(hipSetDevice(e->desc.device));
+    if (int rc = ensure_tuples(e, cap)) return rc;
+    if (int rc = launch_event_sampler(e->dm, e->tuples, cap, n_expected, 0, 0, seed, epoch, e->group_scratch, e->n_drawn_dev, e->st)) return rc;
+    int64_t drawn = 0;
+    ENG_HIP(hipMemcpyAsync(&drawn, e->n_drawn_dev, sizeof drawn, hipMemcpyDeviceToHost, e->st));
+    ENG_HIP(hipStreamSynchronize(e->st));
+    *n_out = std::min(drawn, cap);
+    ENG_HIP(hipMemcpy(out, e->tuples, sizeof(int4) * (size_t)*n_out, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -626,21 +730,33 @@ extern "C" int rec_set_option(rec_engine* e, const char* name, int64_t value)
     if (s == "chunk") { if (value < 1) { rec_set_error("chunk must be positive"); return -1; } e->chunk = value; }
     else if (s == "atomic") e->atomic = value == 1 ? 0x1ff : (int)value;  // 1 = every row; else a mask: bit r = row r of the tuple, bit 8 = biases
     else if (s == "profile") e->profile = value != 0;
+    else if (s == "overlap") {
+        ENG_HIP(hipSetDevice(e->desc.device));
+        ENG_HIP(hipStreamSynchronize(e->st)); ENG_HIP(hipStreamSynchronize(e->st2));
+        e->overlap = value != 0; e->consumed_valid[0] = e->consumed_valid[1] = false;
+    }
     else if (s == "stale_window") { if (value < 0) { rec_set_error("stale_window must be >= 0"); return -1; } e->stale_window = value; }
     else if (s == "global_cap") { if (value < 1) { rec_set_error("global_cap must be positive"); return -1; } e->global_cap = value; }
     else if (s == "global_window") { if (value < 1) { rec_set_error("global_window must be positive"); return -1; } e->global_window = value; }
     else if (s == "update_policy") {
         // 0 exact: every row and bias is scattered with float atomics (sums of all contributions);
-        // 1 hybrid: rows indexed by user are stored plainly (a user is rarely in flight twice), item rows and
-        //   biases use atomics, except for the few items drawn so often (>= 1/1024 of the positives) that
-        //   their atomics would serialize on one address - those are stored plainly too;
+        // 1 hybrid: rows indexed by user and the item biases are stored plainly (a user is rarely in flight twice;
+        //   a 4-byte bias atomic costs a whole 64-byte memory-side request and, measured, buys no accuracy), item
+        //   rows use atomics, except for the few items drawn so often (>= 1/1024 of the positives) that their
+        //   atomics would serialize on one address - those are stored plainly too;
         // 2 plain: classic racy Hogwild stores everywhere
+        e->group = 0;
         if (value == 0) { e->atomic = 0x1ff; return rec_set_option(e, "hot_count", 0); }
         if (value == 2) { e->atomic = 0; return rec_set_option(e, "hot_count", 0); }
         if (value != 1) { rec_set_error("update_policy must be 0, 1 or 2"); return -1; }
-        e->atomic = e->desc.model == REC_MC ? 0x1ff : 0x1fe;
+        e->atomic = e->desc.model == REC_MC ? 0x0ff : 0x0fe;
         return rec_set_option(e, "hot_count", std::max<int64_t>(1, e->steps_per_epoch / 1024));
     }
+    else if (s == "run_shared") { if (value < 1) { rec_set_error("run_shared must be positive"); return -1; } e->run_policy.shared = (int)value; }
+    else if (s == "run_hot") { if (value < 1) { rec_set_error("run_hot must be positive"); return -1; } e->run_policy.hot = (int)value; }
+    else if (s == "run_hot_atomic") e->run_policy.hot_atomic = value != 0;
+    else if (s == "run_segment") { if (value < 0) { rec_set_error("run_segment must be >= 0"); return -1; } e->run_segment = value; }
+    else if (s == "group_by_item") { if (value < 0 || value > 3) { rec_set_error("group_by_item must be 0..3"); return -1; } e->group = (int)value; }
     else if (s == "hot_count") {
         // items with at least `value` training occurrences are "hot" (0 = none)
         ENG_HIP(hipSetDevice(e->desc.device));
@@ -653,7 +769,7 @@ extern "C" int rec_set_option(rec_engine* e, const char* name, int64_t value)
 
 extern "C" int rec_kernel_stats(rec_engine* e, int which, double* total_ms, int64_t* launches)
 {
-    if (!e || which < 0 || which > 2) { rec_set_error("bad argument"); return -1; }
+    if (!e || which < 0 || which > 3) { rec_set_error("bad argument"); return -1; }
     ENG_HIP(hipSetDevice(e->desc.device));
     ENG_HIP(hipStreamSynchronize(e->st));
     for (auto& p : e->pending[which]) {

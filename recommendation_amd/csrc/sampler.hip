@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256) sampler_kernel(DevModel m, int4* __restri
         const int pos = m.succ_item[a + bounded(rng.next(), (uint32_t)cnt)];
         const int32_t* ss = m.sset_item + m.sset_off[e]; const int ns = (int)(m.sset_off[e + 1] - m.sset_off[e]);
         int neg = 0;
-        for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (!sorted_contains(ss, ns, neg)) break; }
+        for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (!filter_may_contain(m.neg_filter, e, neg) || !sorted_contains(ss, ns, neg)) break; }
         t = make_int4(e, pos, neg, 0);
     } else {
         const int64_t so = m.seq_off[e]; const int nu = (int)(m.seq_off[e + 1] - so);
@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(256) sampler_kernel(DevModel m, int4* __restri
             // BPRMF.cpp:74-83, 135-143
             const int pos = seq[bounded(rng.next(), (uint32_t)nu)];
             int neg = 0;
-            for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (!sorted_contains(clk, nc, neg)) break; }
+            for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (!filter_may_contain(m.neg_filter, e, neg) || !sorted_contains(clk, nc, neg)) break; }
             t = make_int4(e, pos, neg, 0);
         } else if constexpr (MODEL == REC_FPMC || MODEL == REC_PRME || MODEL == REC_FOSSIL_SIMPLE || MODEL == REC_HRM_AVG ||
                              MODEL == REC_HRM_MAX) {
@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256) sampler_kernel(DevModel m, int4* __restri
             // TransRec.cpp:188-199
             const int p = (int)bounded(rng.next(), (uint32_t)(nu - 1));
             int neg = 0;
-            for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (!sorted_contains(clk, nc, neg)) break; }
+            for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (!filter_may_contain(m.neg_filter, e, neg) || !sorted_contains(clk, nc, neg)) break; }
             t = make_int4(e, seq[p], seq[p + 1], neg);
         } else if constexpr (MODEL == REC_FOSSIL) {
             // Fossil.cpp:282-293: target position 1..nu-1, negative outside {pos} + the <= L previous items
@@ -113,6 +113,160 @@ int launch_sampler(const DevModel& m, int4* tuples, int64_t n, int64_t first_ste
     default: rec_set_error("model has no sampler"); return -1;
     }
 #undef SAMPLER_CASE
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ event-major sampling
+// The tuple-major sampler draws an owner uniformly and then one of the owner's events (a training
+// position; for MC a transition) uniformly: event e is hit with probability w_e / n_elig per tuple,
+// w_e = 1 / (events of its owner).  n independent tuples therefore contain event e Binomial(n, p_e)
+// times; here every event draws its own count Poisson(n * p_e) instead - the same process with the
+// total Poisson(n) rather than exactly n (relative spread n^-1/2) - which needs no communication
+// between events.  The events are stored ordered by positive item, so the chunk comes out grouped by
+// positive item without a sort.  Negatives are drawn per tuple exactly as in sampler_kernel.
+constexpr int EV_PER_THREAD = 4, EV_TILE = 256 * EV_PER_THREAD;
+
+__device__ __forceinline__ int poisson_draw(float lam, uint32_t r0, uint32_t r1)
+{
+    if (!(lam > 0.f)) return 0;
+    const float u = ((float)(r0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    if (lam < 64.f) {
+        // inversion by sequential search
+        float p = __expf(-lam), s = p; int k = 0;
+        while (u > s && k < 512) { k++; p *= lam / (float)k; s += p; }
+        return k;
+    }
+    // normal approximation with continuity correction
+    const float u2 = (float)(r1 >> 8) * (1.0f / 16777216.0f);
+    const float z = sqrtf(-2.f * __logf(u)) * __cosf(6.28318530718f * u2);
+    const float k = floorf(lam + sqrtf(lam) * z + 0.5f);
+    return k < 0.f ? 0 : (int)k;
+}
+
+__device__ __forceinline__ int event_count(const DevModel& m, int64_t e, float scale, uint64_t seed, uint64_t epoch, uint64_t chunk_no)
+{
+    if (e >= m.n_ev) return 0;
+    Rng rng(seed ^ 0x9E3779B97F4A7C15ull, epoch, (chunk_no << 40) | (uint64_t)e);
+    const uint32_t r0 = rng.next(), r1 = rng.next();
+    return poisson_draw(scale * m.ev_w[e], r0, r1);
+}
+
+__device__ __forceinline__ int block_exclusive_scan_256(int x, int* total)
+{
+    __shared__ int wsum[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(inc, o, 64); if (lane >= o) inc += y; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int q = 0; q < wv; q++) base += wsum[q];
+    *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    return base + inc - x;
+}
+
+__global__ void __launch_bounds__(256) event_count_kernel(DevModel m, float scale, uint64_t seed, uint64_t epoch, uint64_t chunk_no,
+                                                         int64_t* __restrict__ block_sum)
+{
+    const int64_t base = (int64_t)blockIdx.x * EV_TILE + threadIdx.x * EV_PER_THREAD;
+    int s = 0;
+#pragma unroll
+    for (int q = 0; q < EV_PER_THREAD; q++) s += event_count(m, base + q, scale, seed, epoch, chunk_no);
+    int total;
+    (void)block_exclusive_scan_256(s, &total);
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = total;
+}
+
+// exclusive scan of block_sum[0, nblocks) in place by one block; *n_out = the total
+__global__ void __launch_bounds__(256) event_scan_kernel(int64_t* __restrict__ block_sum, int64_t nblocks, int64_t* __restrict__ n_out)
+{
+    __shared__ int64_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    // a thread owns 16 consecutive sums per round: 4096 per round
+    for (int64_t t0 = 0; t0 < nblocks; t0 += 4096) {
+        const int64_t b = t0 + threadIdx.x * 16;
+        int64_t x[16]; int s = 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) { x[q] = b + q < nblocks ? block_sum[b + q] : 0; s += (int)x[q]; }
+        int total;
+        const int ex = block_exclusive_scan_256(s, &total);
+        int64_t run = carry_s + ex;
+#pragma unroll
+        for (int q = 0; q < 16; q++) { if (b + q < nblocks) block_sum[b + q] = run; run += x[q]; }
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_out = carry_s;
+}
+
+template <int MODEL>
+__global__ void __launch_bounds__(256) event_emit_kernel(DevModel m, int4* __restrict__ out, int64_t cap, float scale, int64_t first_step,
+                                                        uint64_t chunk_no, uint64_t seed, uint64_t epoch,
+                                                        const int64_t* __restrict__ block_off)
+{
+    __shared__ int prefix[EV_TILE + 1];
+    const int64_t ebase = (int64_t)blockIdx.x * EV_TILE;
+    int c[EV_PER_THREAD], s = 0;
+#pragma unroll
+    for (int q = 0; q < EV_PER_THREAD; q++) { c[q] = event_count(m, ebase + threadIdx.x * EV_PER_THREAD + q, scale, seed, epoch, chunk_no); s += c[q]; }
+    int total;
+    int ex = block_exclusive_scan_256(s, &total);
+#pragma unroll
+    for (int q = 0; q < EV_PER_THREAD; q++) { prefix[threadIdx.x * EV_PER_THREAD + q] = ex; ex += c[q]; }
+    if (threadIdx.x == 255) prefix[EV_TILE] = ex;
+    __syncthreads();
+    const int64_t obase = block_off[blockIdx.x];
+    for (int j = threadIdx.x; j < total; j += 256) {
+        // the event this tuple belongs to: last le with prefix[le] <= j
+        int lo = 0, hi = EV_TILE;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (prefix[mid] <= j) lo = mid; else hi = mid; }
+        const int4 ev = m.ev[ebase + lo];
+        const int64_t oi = obase + j;
+        if (oi >= cap) continue;
+        Rng rng(seed, epoch, (uint64_t)(first_step + oi));
+        int neg = 0;
+        int4 t;
+        if constexpr (MODEL == REC_BPRMF) {
+            const int32_t* clk = m.clk_item + m.clk_off[ev.x]; const int nc = (int)(m.clk_off[ev.x + 1] - m.clk_off[ev.x]);
+            for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (!filter_may_contain(m.neg_filter, ev.x, neg) || !sorted_contains(clk, nc, neg)) break; }
+            t = make_int4(ev.x, ev.z, neg, 0);
+        } else if constexpr (MODEL == REC_MC) {
+            const int32_t* ss = m.sset_item + m.sset_off[ev.x]; const int ns = (int)(m.sset_off[ev.x + 1] - m.sset_off[ev.x]);
+            for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (!filter_may_contain(m.neg_filter, ev.x, neg) || !sorted_contains(ss, ns, neg)) break; }
+            t = make_int4(ev.x, ev.z, neg, 0);
+        } else {
+            for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (neg != ev.z) break; }
+            t = make_int4(ev.x, ev.y, ev.z, neg);
+        }
+        out[oi] = t;
+    }
+}
+
+size_t event_scratch_bytes(int64_t n_ev)
+{
+    return sizeof(int64_t) * (size_t)((n_ev + EV_TILE - 1) / EV_TILE + 8);
+}
+
+int launch_event_sampler(const DevModel& m, int4* tuples, int64_t cap, int64_t n_expected, int64_t first_step, uint64_t chunk_no,
+                         uint64_t seed, uint64_t epoch, void* scratch, int64_t* n_out_dev, hipStream_t st)
+{
+    if (m.n_ev <= 0 || m.n_elig <= 0) { rec_set_error("no sampling events for this model"); return -1; }
+    const int64_t nblocks = (m.n_ev + EV_TILE - 1) / EV_TILE;
+    int64_t* block_sum = (int64_t*)scratch;
+    const float scale = (float)((double)n_expected / (double)m.n_elig);
+    hipLaunchKernelGGL(event_count_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, m, scale, seed, epoch, chunk_no, block_sum);
+    hipLaunchKernelGGL(event_scan_kernel, dim3(1), dim3(256), 0, st, block_sum, nblocks, n_out_dev);
+#define EMIT_CASE(M) case M: hipLaunchKernelGGL(event_emit_kernel<M>, dim3((unsigned)nblocks), dim3(256), 0, st, m, tuples, cap, scale, first_step, chunk_no, seed, epoch, (const int64_t*)block_sum); break;
+    switch (m.model) {
+        EMIT_CASE(REC_BPRMF) EMIT_CASE(REC_MC) EMIT_CASE(REC_FPMC) EMIT_CASE(REC_PRME) EMIT_CASE(REC_HRM_AVG) EMIT_CASE(REC_HRM_MAX)
+    default: rec_set_error("the event-major sampler is not available for this model"); return -1;
+    }
+#undef EMIT_CASE
     HIP_TRY(hipGetLastError());
     return 0;
 }

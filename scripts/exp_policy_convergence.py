@@ -1,0 +1,66 @@
+"""Accuracy per epoch of the scatter policies on a mid-size synthetic corpus (no CPU reference at
+this scale: policy 0 = float atomics on every row, tuple-major sampling, is the yardstick)."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import recommendation_amd as ra  # noqa: E402
+from recommendation_amd.capi import F32  # noqa: E402
+from bench import make_synthetic  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--users", type=int, default=200_000)
+    ap.add_argument("--items", type=int, default=50_000)
+    ap.add_argument("--clicks", type=int, default=20_000_000)
+    ap.add_argument("--k", type=int, default=64)
+    ap.add_argument("--epochs", type=int, default=20)
+    ap.add_argument("--every", type=int, default=5)
+    ap.add_argument("--model", default="BPRMF")
+    ap.add_argument("--lr", type=float, default=0.05)
+    ap.add_argument("--chunk", type=int, default=1 << 22)
+    ap.add_argument("--variants", default="0:0,1:0,1:2,2:0")
+    args = ap.parse_args()
+    import torch
+    seq_off, seq_item, test, val, _ = make_synthetic(args.users, args.items, args.clicks, 7, torch.device("cuda:0"))
+    for var in args.variants.split(","):
+        mask = None
+        if var.startswith("m"):   # m<hexmask>: hybrid policy's hot exemption with this atomic mask
+            mask, var = int(var[1:], 16), "1:0"
+        policy, group, *rest = (int(x) for x in var.split(":"))
+        eng = ra.Engine(args.model, args.items, seq_off, seq_item, test, val, K=args.k, lam=0.01, bias_reg=0.01, alpha=0.5, precision=F32)
+        eng.set_option("update_policy", policy)
+        eng.set_option("group_by_item", group)
+        if mask is not None:
+            eng.set_option("atomic", mask)
+        eng.set_option("chunk", args.chunk)
+        for name, v in zip(("run_hot", "run_hot_atomic", "run_shared"), rest):
+            eng.set_option(name, v)
+        eng.set_option("profile", 1)
+        eng.init_params(seed=1)
+        t0 = time.perf_counter()
+        line = []
+        for ep in range(args.epochs):
+            eng.sgd_epoch(args.lr, eng.steps_per_epoch, seed=5, epoch=ep)
+            if (ep + 1) % args.every == 0:
+                eng.sync()
+                m = eng.eval()[0]
+                line.append(f"ep{ep + 1}: val {m.auc_val:.4f} test {m.auc_test:.4f} hit {m.hit_test:.4f}")
+        eng.sync()
+        t_train = time.perf_counter() - t0
+        um, un = eng.kernel_stats(0)
+        sm, sn = eng.kernel_stats(2)
+        W = eng.download()
+        print(f"policy {policy} group {group} {rest} mask {mask}: " + " | ".join(line) + f"  finite={np.isfinite(W).all()} |W|max={np.abs(W).max():.2f} "
+              f"{t_train:.2f}s update {um / max(un, 1):.3f} ms x {un} sampler {sm / max(sn, 1):.3f} ms x {sn}", flush=True)
+        eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -201,6 +201,122 @@ def test_hogwild_equals_sequential_without_collisions(model, prec):
     e.close()
 
 
+RUN_MODELS = ["BPRMF", "MC", "FPMC", "PRME", "HRM_avg", "HRM_max"]
+
+
+def _synthetic_corpus(U, I, rng):
+    """Every user: 3 training items + validation + test item (contents are irrelevant to a replay)."""
+    seq_off = np.arange(U + 1, dtype=np.int64) * 3
+    seq_item = rng.integers(0, I, size=3 * U).astype(np.int32)
+    return seq_off, seq_item, rng.integers(0, I, size=U).astype(np.int32), rng.integers(0, I, size=U).astype(np.int32)
+
+
+@pytest.mark.parametrize("model", RUN_MODELS)
+@pytest.mark.parametrize("prec", [F32, F64])
+def test_run_combining_update_equals_sequential(model, prec):
+    """Tuples grouped by positive item, every other row named once: the run-combining kernel keeps the
+    positive's rows in registers across a run, so the launch must equal the reference's in-order replay.
+    400 runs of 128 tuples: several lane-group segments, runs crossing batch boundaries."""
+    rng = np.random.default_rng(5)
+    n_runs, run = 400, 128
+    n = n_runs * run
+    U, I, K = n, n_runs + 2 * n, 8
+    seq_off, seq_item, test, val = _synthetic_corpus(U, I, rng)
+    pos = np.repeat(np.arange(n_runs), run)
+    neg = n_runs + np.arange(n)
+    prev = n_runs + n + np.arange(n)
+    users = rng.permutation(U)
+    if model == "BPRMF":
+        tuples = np.stack([users, pos, neg, np.zeros(n)], 1)
+    elif model == "MC":
+        tuples = np.stack([prev, pos, neg, np.zeros(n)], 1)
+    else:
+        tuples = np.stack([users, prev, pos, neg], 1)
+    tuples = tuples.astype(np.int32)
+    kw = dict(K=K, L=1, lam=0.05, bias_reg=0.01, relation_reg=0.0, alpha=0.3)
+    o = orc.Oracle(model, U, I, K, seq_off, seq_item, test, val, L=1, lam=0.05, bias_reg=0.01, alpha=0.3)
+    W0 = rng.uniform(-0.5, 0.5, o.nw)
+    if prec == F32:
+        W0 = W0.astype(np.float32).astype(np.float64)
+    ref = o.replay(W0, tuples, 0.05)
+    e = ra.Engine(model, I, seq_off, seq_item, test, val, precision=prec, **kw)
+    e.set_option("update_policy", 0)
+    e.set_option("group_by_item", 1)
+    e.set_option("stale_window", 0)   # one launch: segments stay aligned with the runs
+    e.set_option("run_segment", 64)   # 64 batches of 4 (or 2) tuples per lane group: whole runs
+    e.upload(W0)
+    e.sgd_replay(0.05, tuples, HOGWILD)
+    W1 = e.download()
+    tol = 1e-10 if prec == F64 else 2e-5   # 128 dependent f32 steps per positive row
+    assert rel_err(W1, ref, floor=1e-1) < tol, (model, rel_err(W1, ref, floor=1e-1))
+    # the same launch on shuffled tuples (runs of length one, stale reads) stays close but is not the replay
+    e.upload(W0)
+    e.sgd_replay(0.05, tuples[rng.permutation(n)], HOGWILD)
+    assert np.isfinite(e.download()).all()
+    e.close()
+
+
+@pytest.mark.parametrize("model", RUN_MODELS)
+def test_event_major_sampler_matches_tuple_major_distribution(model):
+    """The event-major sampler (Poisson count per sampling event, output grouped by positive item) must
+    draw from the distribution of the tuple-major sampler: same support, grouped output, Poisson total,
+    and matching frequencies of owners, positives and (owner, previous, positive) events."""
+    g, model, co, ci, labels = fixture_case(model, "toy")
+    e = make_engine(g, model, co, ci, labels, F32)
+    n = 400000
+    a = e.sample_tuples(n, seed=4, epoch=2)
+    b = e.sample_events(n, seed=4, epoch=2)
+    assert abs(len(b) - n) < 6 * n ** 0.5
+    col = 1 if model in ("BPRMF", "MC") else 2
+    assert (np.diff(b[:, col]) >= 0).all()                     # grouped by positive item
+    again = e.sample_events(n, seed=4, epoch=2)
+    assert np.array_equal(b, again)                            # a function of (seed, epoch) only
+    assert not np.array_equal(b[:1000], e.sample_events(n, seed=5, epoch=2)[:1000])
+    ncol = 2 if model in ("BPRMF", "MC") else 3                # the columns that identify the event
+    def freq(x):
+        keys, cnt = np.unique(x[:, :ncol], axis=0, return_counts=True)
+        return {tuple(k): c for k, c in zip(keys.tolist(), cnt.tolist())}
+    fa, fb = freq(a), freq(b)
+    assert set(fb) <= set(fa) or len(set(fb) - set(fa)) < 0.01 * len(fb)   # rare events may be missing from one draw
+    ratio = len(a) / len(b)                                     # the event-major total is Poisson, not fixed
+    z = []
+    for k in set(fa) | set(fb):
+        ca, cb = fa.get(k, 0), fb.get(k, 0) * ratio
+        z.append((ca - cb) / max(1.0, (ca + cb)) ** 0.5)      # difference of two counts with equal means
+    z = np.array(z)
+    assert abs(z.mean()) < 5 / len(z) ** 0.5 and 0.8 < z.std() < 1.2 and np.abs(z).max() < 6, (z.mean(), z.std(), np.abs(z).max(), len(z))
+    # negatives: same support rule and the same marginal
+    neg_a, neg_b = a[:, ncol], b[:, ncol]
+    I = int(g["n_items"])
+    ha, hb = np.bincount(neg_a, minlength=I), np.bincount(neg_b, minlength=I)
+    zz = (ha - hb) / np.maximum(1.0, ha + hb) ** 0.5
+    assert np.abs(zz).max() < 6
+    e.close()
+
+
+@pytest.mark.parametrize("model", RUN_MODELS)
+def test_event_major_epochs_train_like_tuple_major_epochs(model):
+    """Epochs through the event-major sampler and the run-combining kernel (the large-problem path,
+    forced here on the toy corpus) reach the validation AUC of the default path."""
+    g, model, co, ci, labels = fixture_case(model, "toy")
+    res = {}
+    for grp in (0, 2):
+        e = make_engine(g, model, co, ci, labels, F32)
+        e.set_option("group_by_item", grp)
+        if grp == 2:
+            e.set_option("stale_window", 0)
+        e.init_params(3)
+        for ep in range(40):
+            e.sgd_epoch(0.05, e.steps_per_epoch, seed=11, epoch=ep)
+        e.sync()
+        assert np.isfinite(e.download()).all()
+        if grp == 2:
+            drawn, want = e.tuples_drawn, 40 * e.steps_per_epoch
+            assert abs(drawn - want) < 6 * want ** 0.5
+        res[grp] = e.eval()[0].auc_val
+        e.close()
+    assert abs(res[0] - res[2]) < 0.03, res
+
 @pytest.mark.parametrize("model", ["FossilSimple", "Fossil", "REBUS"])
 def test_history_hogwild_single_tuples(model):
     """One tuple per launch: the Hogwild kernels of the history models against updateFactors.
