@@ -298,51 +298,64 @@ template <int KQ> struct TileShape {
 };
 
 template <class T, int KQ, bool TWO, bool STORE>
-__global__ void __launch_bounds__(256) score_count_kernel(EvalDev ev, const T* __restrict__ seg0, const T* __restrict__ seg1,
-                                                          const int32_t* __restrict__ qtest, const int32_t* __restrict__ qval, int I)
+__global__ void __launch_bounds__(256, 2) score_count_kernel(EvalDev ev, const T* __restrict__ seg0, const T* __restrict__ seg1,
+                                                             const int32_t* __restrict__ qtest, const int32_t* __restrict__ qval, int I)
 {
     constexpr int KC = KQ / 4, NI = TileShape<KQ>::NI, MT = TileShape<KQ>::MT, STR = KQ + 2;
     constexpr int PER = NI * KQ / 256;  // tile elements per thread
+    constexpr int QB = 4 * MT * 16;     // queries per block
     __shared__ double tile[NI * STR];
+    __shared__ double tile_b[NI];       // b_j of the tile's items
+    // per-query constants live in LDS, not in registers: the epilogue that reads them runs once per 16 * MT MFMAs,
+    // and the registers they would occupy are what allows two wavefronts per SIMD
+    __shared__ double2 q_thr[QB];       // (threshold, second threshold)
+    __shared__ int2 q_ex[QB];           // (test item, validation item): never counted
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, quad = lane >> 4;
-    const int64_t qbase = ((int64_t)blockIdx.x * 4 + wave) * (MT * 16);
+    const int64_t qblock = (int64_t)blockIdx.x * QB;
+    const int qw = wave * (MT * 16);    // this wavefront's first query inside the block
     const int K1 = ev.K1, K2 = ev.K2;
+
+    for (int i = tid; i < QB; i += 256) {
+        q_thr[i] = make_double2(ev.thr[qblock + i], TWO ? ev.thr2[qblock + i] : 0.0);
+        q_ex[i] = make_int2(qtest[qblock + i], qval[qblock + i]);
+    }
 
     double a[MT][KC];
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-        for (int kc = 0; kc < KC; kc++) a[mt][kc] = ev.Q[(qbase + mt * 16 + col) * KQ + 4 * kc + quad];
+        for (int kc = 0; kc < KC; kc++) a[mt][kc] = ev.Q[(qblock + qw + mt * 16 + col) * KQ + 4 * kc + quad];
 
-    double thr[MT][4], thr2[MT][4];
-    int ex1[MT][4], ex2[MT][4], cnt[MT][4], cnt2[MT][4];
+    int cnt[MT][4], cnt2[MT][4];
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int64_t qi = qbase + mt * 16 + quad + 4 * r;
-            thr[mt][r] = ev.thr[qi]; thr2[mt][r] = TWO ? ev.thr2[qi] : 0.0;
-            ex1[mt][r] = qtest[qi]; ex2[mt][r] = qval[qi];
-            cnt[mt][r] = 0; cnt2[mt][r] = 0;
-        }
+        for (int r = 0; r < 4; r++) { cnt[mt][r] = 0; cnt2[mt][r] = 0; }
 
-    auto fetch = [&](int item0, T (&pre)[PER]) {
+    const bool dense = K1 == KQ;        // one table segment that fills the query width: a tile is one contiguous run
+    auto fetch = [&](int item0, T (&pre)[PER], double& preb) {
+        if (dense && item0 + NI <= I) {
+            const T* src = seg0 + (int64_t)item0 * KQ + tid;
+#pragma unroll
+            for (int p = 0; p < PER; p++) pre[p] = src[256 * p];
+            preb = tid < NI ? ev.bconst[item0 + tid] : 0.0;
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < PER; p++) {
             const int idx = tid + 256 * p, it = idx / KQ, k = idx % KQ;
             const int64_t j = (int64_t)item0 + it;
-            T v = 0;
-            if (j < I) {
-                if (k < K1) v = seg0[j * K1 + k];
-                else if (k < K1 + K2) v = seg1[j * K2 + (k - K1)];
-            }
-            pre[p] = v;
+            // one predicated load per element: the address is selected, not branched on
+            const T* src = k < K1 ? seg0 + j * K1 + k : seg1 + j * K2 + (k - K1);
+            const bool ok = j < I && k < K1 + K2;
+            pre[p] = ok ? *src : (T)0;
         }
+        preb = (tid < NI && item0 + tid < I) ? ev.bconst[item0 + tid] : 0.0;
     };
 
-    T pre[PER];
-    fetch(0, pre);
+    T pre[PER]; double preb;
+    fetch(0, pre, preb);
     for (int item0 = 0; item0 < I; item0 += NI) {
         __syncthreads();
 #pragma unroll
@@ -350,14 +363,14 @@ __global__ void __launch_bounds__(256) score_count_kernel(EvalDev ev, const T* _
             const int idx = tid + 256 * p, it = idx / KQ, k = idx % KQ;
             tile[it * STR + k] = (double)pre[p];
         }
+        if (tid < NI) tile_b[tid] = preb;
         __syncthreads();
-        if (item0 + NI < I) fetch(item0 + NI, pre);
-#pragma unroll
+        if (item0 + NI < I) fetch(item0 + NI, pre, preb);
+#pragma unroll 1
         for (int sub = 0; sub < NI / 16; sub++) {
             const int jj = sub * 16 + col;
             const int j = item0 + jj;
             const bool live = j < I;
-            const double bj = live ? ev.bconst[j] : 0.0;
             double4_t acc[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) acc[mt] = (double4_t){0.0, 0.0, 0.0, 0.0};
@@ -367,15 +380,29 @@ __global__ void __launch_bounds__(256) score_count_kernel(EvalDev ev, const T* _
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt][kc], b, acc[mt], 0, 0, 0);
             }
+            const double bj = tile_b[jj];
+            if (STORE) {
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (live) ev.S[(qblock + qw + mt * 16 + quad + 4 * r) * (int64_t)I + j] = acc[mt][r] + bj;
+                continue;
+            }
+            // all constants first, then straight-line predicate arithmetic: no LDS round trip per element
+            double2 th[MT][4]; int2 ex[MT][4];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) { const int qi = qw + mt * 16 + quad + 4 * r; th[mt][r] = q_thr[qi]; ex[mt][r] = q_ex[qi]; }
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const double s = acc[mt][r] + bj;
-                    if (STORE) { if (live) ev.S[(qbase + mt * 16 + quad + 4 * r) * (int64_t)I + j] = s; continue; }
-                    const bool ok = live && j != ex1[mt][r] && j != ex2[mt][r];
-                    cnt[mt][r] += (ok && thr[mt][r] > s) ? 1 : 0;
-                    if (TWO) cnt2[mt][r] += (ok && thr2[mt][r] > s) ? 1 : 0;
+                    const int ok = (int)live & (int)(j != ex[mt][r].x) & (int)(j != ex[mt][r].y);
+                    cnt[mt][r] += ok & (int)(th[mt][r].x > s);
+                    if (TWO) cnt2[mt][r] += ok & (int)(th[mt][r].y > s);
                 }
         }
     }
@@ -389,7 +416,7 @@ __global__ void __launch_bounds__(256) score_count_kernel(EvalDev ev, const T* _
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) { c += __shfl_xor(c, o, 64); if (TWO) c2 += __shfl_xor(c2, o, 64); }
             if (col == 0) {
-                const int64_t qi = qbase + mt * 16 + quad + 4 * r;
+                const int64_t qi = qblock + qw + mt * 16 + quad + 4 * r;
                 ev.cnt[qi] = c;
                 if (TWO) ev.cnt2[qi] = c2;
             }
