@@ -107,7 +107,7 @@ int rec_sgd_replay(rec_engine* e, double lr, const int32_t* tuples, int64_t n, i
  * the device by a counter-based generator keyed by (seed, epoch, step), applied Hogwild-style */
 int rec_sgd_epoch(rec_engine* e, double lr, int64_t n_steps, uint64_t seed, uint64_t epoch);
 
-/* Large problems ("group_by_item" = 2, the default with the hybrid update policy) draw a chunk by event instead
+/* With "group_by_item" = 2 (off by default: item-sorted order slows convergence) a chunk is drawn by event instead
  * of by tuple: every (user, position) the samplers above can pick yields Poisson(n * P(position)) tuples.  The
  * tuples of a chunk are the same i.i.d. draws, grouped by positive item, and their number is Poisson(n) instead
  * of exactly n.  rec_tuples_drawn: the number of tuples rec_sgd_epoch has applied since rec_create. */
@@ -158,6 +158,9 @@ int rec_table_info(const rec_engine* e, int t, void** dev_ptr, int64_t* rows, in
  *   "group_by_item" 0 = off, 1 = the update kernel combines runs of equal positive items into one scatter,
  *                   2 = 1 + chunks are drawn by event, which groups them by positive item
  *   "run_segment"   batches one lane group of the run-combining kernel walks (0 = automatic)
+ *   "run_shared", "run_hot", "run_hot_atomic"  how many tuples a run of equal positives stays in registers when its
+ *                   item is shared with a neighbouring lane group / fills whole segments, and whether the latter is
+ *                   scattered with atomics (default 128, 32, 0)
  *   "chunk"         tuples sampled per sampler launch (default 2^26)
  *   "overlap"       1 = sample chunk c+1 on a second stream while chunk c is applied (default 0: measured slower)
  *   "stale_window"  tuples per update launch for small catalogs (0 = no limit)
