@@ -144,6 +144,14 @@ int64_t rec_rebus_build_paths(int32_t n_users, int32_t n_items, const int64_t* s
                               const int64_t* lab_off, const int32_t* lab_item, int64_t* path_off,
                               int32_t* path_item);
 
+/* No counterpart in the reference, whose 96-FSUB label files are precomputed and only read (REBUS::loadPST,
+ * REBUS.cpp:3-87): the labels of such a file for the given training sequences - every contiguous run of 1..L
+ * items (oldest first) occurring at least min_count times - as integer sequences ("Root" omitted), in the layout
+ * rec_rebus_build_paths takes.  Returns the number of labels and sets *n_label_items; call with lab_off =
+ * lab_item = NULL to obtain the sizes.  Host only. */
+int64_t rec_fsub_mine(int32_t n_users, int32_t n_items, const int64_t* seq_off, const int32_t* seq_item, int32_t L,
+                      int64_t min_count, int64_t* lab_off, int32_t* lab_item, int64_t* n_label_items);
+
 /* Device tables, for collectives issued by the caller (RCCL through torch.distributed):
  * table t of the model in the reference's flat order.  *dev_ptr points to rows x cols elements
  * of the engine's precision, contiguous.  is_user_table = 1 for tables indexed by user. */

@@ -15,7 +15,7 @@ SEQUENTIAL, HOGWILD = 0, 1
 EXPORTS = ["rec_last_error", "rec_create", "rec_destroy", "rec_sync", "rec_nw", "rec_params_upload",
            "rec_params_download", "rec_params_read", "rec_params_init", "rec_snapshot_best", "rec_restore_best", "rec_sgd_replay",
            "rec_sgd_epoch", "rec_sample_tuples", "rec_sample_events", "rec_tuples_drawn", "rec_steps_per_epoch", "rec_eval", "rec_eval_topk", "rec_eval_sums",
-           "rec_rebus_build_paths", "rec_num_tables", "rec_table_info", "rec_set_option", "rec_kernel_stats"]
+           "rec_rebus_build_paths", "rec_fsub_mine", "rec_num_tables", "rec_table_info", "rec_set_option", "rec_kernel_stats"]
 
 
 class RecCorpus(C.Structure):
@@ -55,6 +55,7 @@ def lib():
         _lib.rec_nw.argtypes = [C.c_void_p]
         _lib.rec_steps_per_epoch.restype = C.c_int64
         _lib.rec_steps_per_epoch.argtypes = [C.c_void_p]
+        _lib.rec_fsub_mine.restype = C.c_int64
         _lib.rec_tuples_drawn.restype = C.c_int64
         _lib.rec_tuples_drawn.argtypes = [C.c_void_p]
         _lib.rec_rebus_build_paths.restype = C.c_int64
@@ -86,6 +87,22 @@ def build_rebus_paths(n_items, seq_off, seq_item, val_item, lab_off, lab_item):
     path_item = np.zeros(max(1, n), np.int32)
     lib().rec_rebus_build_paths(*args, _p(path_off), _p(path_item))
     return path_off, path_item
+
+
+def fsub_mine(n_items, seq_off, seq_item, L, min_count):
+    """Labels of a 96-FSUB file (without 'Root') as (lab_off, lab_item)."""
+    seq_off = np.ascontiguousarray(seq_off, np.int64)
+    seq_item = np.ascontiguousarray(seq_item, np.int32)
+    U = len(seq_off) - 1
+    total = C.c_int64(0)
+    args = (C.c_int32(U), C.c_int32(n_items), _p(seq_off), _p(seq_item), C.c_int32(L), C.c_int64(min_count))
+    n = lib().rec_fsub_mine(*args, None, None, C.byref(total))
+    if n < 0:
+        _check(-1)
+    lab_off = np.zeros(n + 1, np.int64)
+    lab_item = np.zeros(max(1, total.value), np.int32)
+    lib().rec_fsub_mine(*args, _p(lab_off), _p(lab_item), C.byref(total))
+    return lab_off, lab_item[:total.value]
 
 
 class Engine:

@@ -91,3 +91,77 @@ extern "C" int64_t rec_rebus_build_paths(int32_t n_users, int32_t n_items, const
     }
     return run;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Label set of a 96-FSUB file.  The reference ships these files precomputed and holds no code that
+// writes them; REBUS::loadPST (REBUS.cpp:3-87) only reads them.  Their content, checked against the
+// bundled ML-5 files: every contiguous run of 1..L items of the training sequences (oldest item
+// first) that occurs at least min_count times, counted over all users and positions.
+// Mined level by level: a run of length l is a frequent run of length l-1 plus one item, so a
+// position only needs the node id of the frequent run that starts there (-1: none) and the count
+// map is keyed by (that node, next item).  A run can only be frequent if the run that starts one
+// position later (its suffix) is frequent as well, which prunes most candidates.
+namespace {
+struct FsubNode { int64_t parent; int32_t item; int32_t len; };
+}
+
+extern "C" int64_t rec_fsub_mine(int32_t n_users, int32_t n_items, const int64_t* seq_off, const int32_t* seq_item, int32_t L,
+                                 int64_t min_count, int64_t* lab_off, int32_t* lab_item, int64_t* n_label_items)
+{
+    if (!seq_off || !seq_item || !n_label_items) { rec_set_error("null argument"); return -1; }
+    if (L < 1 || min_count < 1) { rec_set_error("L and min_count must be positive"); return -1; }
+    const int64_t E = seq_off[n_users];
+    std::vector<FsubNode> nodes;
+    std::vector<int64_t> cur(E, -1), nxt(E, -1);
+    // level 1
+    {
+        std::vector<int64_t> cnt(n_items, 0), id(n_items, -1);
+        for (int64_t p = 0; p < E; p++) {
+            if (seq_item[p] < 0 || seq_item[p] >= n_items) { rec_set_error("item id out of range in seq_item"); return -1; }
+            cnt[seq_item[p]]++;
+        }
+        for (int32_t i = 0; i < n_items; i++)
+            if (cnt[i] >= min_count) { id[i] = (int64_t)nodes.size(); nodes.push_back({-1, i, 1}); }
+        for (int64_t p = 0; p < E; p++) cur[p] = id[seq_item[p]];
+    }
+    for (int32_t len = 2; len <= L; len++) {
+        std::unordered_map<uint64_t, int64_t> cnt;
+        auto key_at = [&](int32_t u, int64_t p) -> int64_t {   // -1: no candidate of this length starts at p
+            if (p + len > seq_off[u + 1] || cur[p] < 0 || cur[p + 1] < 0) return -1;
+            return (int64_t)(((uint64_t)cur[p] << 32) | (uint32_t)seq_item[p + len - 1]);
+        };
+        if (nodes.size() >= ((uint64_t)1 << 31)) { rec_set_error("too many labels"); return -1; }
+        for (int32_t u = 0; u < n_users; u++)
+            for (int64_t p = seq_off[u]; p < seq_off[u + 1]; p++) { const int64_t k = key_at(u, p); if (k >= 0) cnt[(uint64_t)k]++; }
+        std::unordered_map<uint64_t, int64_t> id;
+        for (const auto& kv : cnt)
+            if (kv.second >= min_count) {
+                id[kv.first] = (int64_t)nodes.size();
+                nodes.push_back({(int64_t)(kv.first >> 32), (int32_t)(uint32_t)kv.first, len});
+            }
+        if (id.empty()) break;
+        std::fill(nxt.begin(), nxt.end(), -1);
+        for (int32_t u = 0; u < n_users; u++)
+            for (int64_t p = seq_off[u]; p < seq_off[u + 1]; p++) {
+                const int64_t k = key_at(u, p);
+                if (k < 0) continue;
+                auto it = id.find((uint64_t)k);
+                if (it != id.end()) nxt[p] = it->second;
+            }
+        cur.swap(nxt);
+    }
+    int64_t total = 0;
+    for (const FsubNode& n : nodes) total += n.len;
+    *n_label_items = total;
+    if (lab_off && lab_item) {
+        int64_t at = 0;
+        for (size_t i = 0; i < nodes.size(); i++) {
+            lab_off[i] = at;
+            int64_t w = at + nodes[i].len - 1;
+            for (int64_t n = (int64_t)i; n >= 0; n = nodes[n].parent) lab_item[w--] = nodes[n].item;
+            at += nodes[i].len;
+        }
+        lab_off[nodes.size()] = at;
+    }
+    return (int64_t)nodes.size();
+}

@@ -46,3 +46,47 @@ def test_rebus_path_builder_matches_reference():
                 path = pi[po[ctx]:po[ctx + 1]]
                 flat.append(len(path)); flat.extend(path.tolist())
         assert np.array_equal(np.array(flat, np.int32), g["paths_flat"]), tag
+
+
+def _label_set(lab_off, lab_item):
+    return {"-".join(str(x) for x in lab_item[lab_off[i]:lab_off[i + 1]]) for i in range(len(lab_off) - 1)}
+
+
+def test_fsub_miner_reproduces_the_bundled_label_files():
+    """The reference ships its 96-FSUB files precomputed; the miner must reproduce them from the click file:
+    ML-5 minCount 2 / L 3 (2 470 labels + Root) and the toy file written by oracle/make_golden.py."""
+    from tests.golden_util import read_labels
+    for tag, fam, fname, mc, L in (("REBUS_mc2_L3", "ml5", "ML1M-atmost-5_root_fsub_minCount_2_L_3.txt.gz", 2, 3),
+                                   ("REBUS", "toy", "toy_root_fsub_minCount_2_L_3.txt", 2, 3)):
+        g, model, co, ci, labels = fixture_case(tag, fam)
+        seq_off, seq_item, test, val = orc.split(co, ci)
+        want = {x for x in read_labels(fname) if x and x != "Root"}
+        lo, li = ra.fsub_mine(int(g["n_items"]), seq_off, seq_item, L, mc)
+        assert _label_set(lo, li) == want, tag
+    # monotone in both arguments
+    g, model, co, ci, labels = fixture_case("REBUS", "toy")
+    seq_off, seq_item, test, val = orc.split(co, ci)
+    I = int(g["n_items"])
+    a = _label_set(*ra.fsub_mine(I, seq_off, seq_item, 2, 2))
+    b = _label_set(*ra.fsub_mine(I, seq_off, seq_item, 3, 2))
+    c = _label_set(*ra.fsub_mine(I, seq_off, seq_item, 3, 3))
+    assert a <= b and c <= b and all(x.count("-") <= 1 for x in a)
+
+
+def test_fsub_mine_tool_writes_the_file_loadpst_expects(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "recommendation_amd", "fsub_mine")
+    assert os.path.exists(tool), "build recommendation_amd/host first"
+    (tmp_path / "01-Data").mkdir(); (tmp_path / "96-FSUB").mkdir()
+    import shutil
+    shutil.copy(os.path.join(root, "tests", "golden", "toy_clicks.txt"), tmp_path / "01-Data" / "toy.txt")
+    r = subprocess.run([tool, "01-Data/toy.txt", "0", "0", "2", "3"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = [x for x in open(tmp_path / "96-FSUB" / "toy_root_fsub_minCount_2_L_3.txt").read().split("\n") if x]
+    want = [x for x in open(os.path.join(root, "tests", "golden", "toy_root_fsub_minCount_2_L_3.txt")).read().split("\n") if x]
+    assert got[0] == "Root" and set(got) == set(want) and len(got) == len(want)
+    r = subprocess.run([tool, "01-Data/toy.txt", "0", "0", "1", "1"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0
+    got = [x for x in open(tmp_path / "96-FSUB" / "toy_root_fsub_minCount_1_L_1.txt").read().split("\n") if x]
+    assert got == [str(i) for i in range(40)]
