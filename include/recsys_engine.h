@@ -127,6 +127,15 @@ int64_t rec_steps_per_epoch(const rec_engine* e);
  * evaluated).  xpos_out (optional): per user x_test, x_val. */
 int rec_eval(rec_engine* e, int topn, rec_metrics* out, int32_t* counts_out, double* xpos_out);
 
+/* replaces: model::sampleAUC / Fossil::sampleAUC / REBUS::sampleAUC (src/model.cpp:100-167): the validation estimate
+ * over n_sampled candidate draws instead of the whole catalog (the reference draws 2000 per user from the global
+ * rand() stream; here one draw of n_sampled items, with replacement, is shared by all users - the same estimator
+ * of the mean, computed by the same kernels on gathered item rows).  Draws that hit a clicked or held-out item are
+ * skipped, not replaced (max <= n_sampled), as in the reference.  counts_out (optional): as rec_eval;
+ * sampled_out (optional): the n_sampled item ids. */
+int rec_eval_sampled(rec_engine* e, int topn, int32_t n_sampled, uint64_t seed, rec_metrics* out, int32_t* counts_out,
+                     int32_t* sampled_out);
+
 /* The ranking behind HIT@k (src/model.cpp:52-58): for every listed user, the k best-scored items among the
  * candidates of model::AUC plus the context's positive, for the validation (index 0) and the test (index 1)
  * context.  items_out / scores_out: [n_users][2][k], best first; -1 / -inf when fewer than k exist. k <= 256. */

@@ -14,7 +14,7 @@ SEQUENTIAL, HOGWILD = 0, 1
 
 EXPORTS = ["rec_last_error", "rec_create", "rec_destroy", "rec_sync", "rec_nw", "rec_params_upload",
            "rec_params_download", "rec_params_read", "rec_params_init", "rec_snapshot_best", "rec_restore_best", "rec_sgd_replay",
-           "rec_sgd_epoch", "rec_sample_tuples", "rec_sample_events", "rec_tuples_drawn", "rec_steps_per_epoch", "rec_eval", "rec_eval_topk", "rec_eval_sums",
+           "rec_sgd_epoch", "rec_sample_tuples", "rec_sample_events", "rec_tuples_drawn", "rec_steps_per_epoch", "rec_eval", "rec_eval_sampled", "rec_eval_topk", "rec_eval_sums",
            "rec_rebus_build_paths", "rec_fsub_mine", "rec_num_tables", "rec_table_info", "rec_set_option", "rec_kernel_stats"]
 
 
@@ -201,6 +201,14 @@ class Engine:
         xpos = np.zeros((self.n_users, 2), np.float64) if want_xpos else None
         _check(lib().rec_eval(self.handle, C.c_int(topn), C.byref(m), _p(counts), _p(xpos)))
         return m, counts, xpos
+
+    def eval_sampled(self, n_sampled=2000, seed=0, topn=50):
+        m = Metrics()
+        counts = np.zeros((self.n_users, 3), np.int32)
+        sampled = np.zeros(n_sampled, np.int32)
+        _check(lib().rec_eval_sampled(self.handle, C.c_int(topn), C.c_int32(n_sampled), C.c_uint64(seed), C.byref(m), _p(counts),
+                                      _p(sampled)))
+        return m, counts, sampled
 
     def eval_topk(self, users, k=50):
         users = np.ascontiguousarray(users, np.int32)

@@ -95,10 +95,12 @@ int launch_event_sampler(const DevModel& m, int4* tuples, int64_t cap, int64_t n
 
 int launch_mark_hot(const DevModel& m, uint8_t* hot, int64_t min_count, hipStream_t st);
 
-// Full-catalog evaluation of the users in m.eval_users.  counts_host: [U][3] (count_val, count_test,
-// max; -1 for users not evaluated); xpos_host (optional): [U][2] (x_test, x_val).
+// Evaluation of the users in m.eval_users against the whole catalog (n_subset = 0) or against the n_subset items
+// listed in subset_host (host memory, repetitions allowed: every occurrence is one scored candidate).
+// counts_host: [U][3] (count_val, count_test, max; -1 for users not evaluated); xpos_host (optional): [U][2]
+// (x_test, x_val).
 int eval_run(const DevModel& m, int precision, int32_t* counts_host, double* xpos_host, hipStream_t st,
-             double* score_ms, int64_t* score_launches, bool profile);
+             double* score_ms, int64_t* score_launches, bool profile, const int32_t* subset_host, int n_subset);
 
 // The k best-scored items of the validation and of the test context of every listed user:
 // items_host / scores_host are [n_users][2][k] (context 0 = validation, 1 = test; -1 / -inf past the end).

@@ -657,19 +657,16 @@ static void reduce_metrics(const rec_engine* e, const int32_t* counts, int topn,
     }
 }
 
-static int eval_counts(rec_engine* e, std::vector<int32_t>& counts, double* xpos)
+static int eval_counts(rec_engine* e, std::vector<int32_t>& counts, double* xpos, const int32_t* subset = nullptr, int n_subset = 0)
 {
     ENG_HIP(hipSetDevice(e->desc.device));
     ENG_HIP(hipStreamSynchronize(e->st));
     counts.resize((size_t)e->U * 3);
-    return eval_run(e->dm, e->desc.precision, counts.data(), xpos, e->st, &e->ms[1], &e->launches[1], e->profile != 0);
+    return eval_run(e->dm, e->desc.precision, counts.data(), xpos, e->st, &e->ms[1], &e->launches[1], e->profile != 0, subset, n_subset);
 }
 
-extern "C" int rec_eval(rec_engine* e, int topn, rec_metrics* out, int32_t* counts_out, double* xpos_out)
+static void metrics_from_counts(const rec_engine* e, const std::vector<int32_t>& counts, int topn, rec_metrics* out)
 {
-    if (!e || !out) { rec_set_error("null argument"); return -1; }
-    std::vector<int32_t> counts;
-    if (int rc = eval_counts(e, counts, xpos_out)) return rc;
     double s[8];
     reduce_metrics(e, counts.data(), topn, s);
     const double n = s[7];
@@ -685,6 +682,38 @@ extern "C" int rec_eval(rec_engine* e, int topn, rec_metrics* out, int32_t* coun
         var += dlt * dlt;
     }
     out->var_test = var / n;
+}
+
+extern "C" int rec_eval_sampled(rec_engine* e, int topn, int32_t n_sampled, uint64_t seed, rec_metrics* out, int32_t* counts_out,
+                                int32_t* sampled_out)
+{
+    if (!e || !out) { rec_set_error("null argument"); return -1; }
+    if (n_sampled < 1) { rec_set_error("n_sampled must be positive"); return -1; }
+    // one draw of n_sampled items, with replacement, shared by all users (splitmix64)
+    std::vector<int32_t> sub(n_sampled);
+    uint64_t x = seed + 0x9E3779B97F4A7C15ull;
+    for (int i = 0; i < n_sampled; i++) {
+        x += 0x9E3779B97F4A7C15ull;
+        uint64_t z = x; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        sub[i] = (int32_t)((z >> 11) % (uint64_t)e->I);
+    }
+    std::vector<int32_t> counts;
+    if (int rc = eval_counts(e, counts, nullptr, sub.data(), n_sampled)) return rc;
+    // a user whose sampled candidates are all excluded has no estimate: leave it out, as a division by max = 0 would
+    for (int u = 0; u < e->U; u++)
+        if (counts[3 * (size_t)u + 2] == 0) counts[3 * (size_t)u] = counts[3 * (size_t)u + 1] = counts[3 * (size_t)u + 2] = -1;
+    metrics_from_counts(e, counts, topn, out);
+    if (counts_out) memcpy(counts_out, counts.data(), sizeof(int32_t) * counts.size());
+    if (sampled_out) memcpy(sampled_out, sub.data(), sizeof(int32_t) * sub.size());
+    return 0;
+}
+
+extern "C" int rec_eval(rec_engine* e, int topn, rec_metrics* out, int32_t* counts_out, double* xpos_out)
+{
+    if (!e || !out) { rec_set_error("null argument"); return -1; }
+    std::vector<int32_t> counts;
+    if (int rc = eval_counts(e, counts, xpos_out)) return rc;
+    metrics_from_counts(e, counts, topn, out);
     if (counts_out) memcpy(counts_out, counts.data(), sizeof(int32_t) * counts.size());
     return 0;
 }

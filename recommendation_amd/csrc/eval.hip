@@ -31,6 +31,11 @@ struct EvalDev {
     double* aq;                // [nq_pad] a_q of every query (top-k output only)
     double* S;                 // [nq_pad][I] relative scores b_j + <q', T_j> (top-k only)
     int force2;                // 1: one query per (user, context) even for models whose two contexts share q
+    // sampled evaluation: the scored columns are a multiset of items instead of the whole catalog
+    const int32_t* col_item;   // [columns] item id behind every scored column (null: column j is item j)
+    const double* col_b;       // [columns] b of every scored column (bconst gathered; = bconst when all items are scored)
+    const int32_t* item_mult;  // [I] how often an item occurs among the columns (null: once)
+    int n_cols;                // number of scored columns
 };
 
 #define E REC_MAX_EPL
@@ -306,6 +311,7 @@ __global__ void __launch_bounds__(256, 2) score_count_kernel(EvalDev ev, const T
     constexpr int QB = 4 * MT * 16;     // queries per block
     __shared__ double tile[NI * STR];
     __shared__ double tile_b[NI];       // b_j of the tile's items
+    __shared__ int tile_id[NI];         // their item ids (the column index unless a subset is scored)
     // per-query constants live in LDS, not in registers: the epilogue that reads them runs once per 16 * MT MFMAs,
     // and the registers they would occupy are what allows two wavefronts per SIMD
     __shared__ double2 q_thr[QB];       // (threshold, second threshold)
@@ -334,12 +340,13 @@ __global__ void __launch_bounds__(256, 2) score_count_kernel(EvalDev ev, const T
         for (int r = 0; r < 4; r++) { cnt[mt][r] = 0; cnt2[mt][r] = 0; }
 
     const bool dense = K1 == KQ;        // one table segment that fills the query width: a tile is one contiguous run
-    auto fetch = [&](int item0, T (&pre)[PER], double& preb) {
+    auto fetch = [&](int item0, T (&pre)[PER], double& preb, int& preid) {
+        preid = (tid < NI && item0 + tid < I) ? (ev.col_item ? ev.col_item[item0 + tid] : item0 + tid) : -2;
         if (dense && item0 + NI <= I) {
             const T* src = seg0 + (int64_t)item0 * KQ + tid;
 #pragma unroll
             for (int p = 0; p < PER; p++) pre[p] = src[256 * p];
-            preb = tid < NI ? ev.bconst[item0 + tid] : 0.0;
+            preb = tid < NI ? ev.col_b[item0 + tid] : 0.0;
             return;
         }
 #pragma unroll
@@ -351,11 +358,11 @@ __global__ void __launch_bounds__(256, 2) score_count_kernel(EvalDev ev, const T
             const bool ok = j < I && k < K1 + K2;
             pre[p] = ok ? *src : (T)0;
         }
-        preb = (tid < NI && item0 + tid < I) ? ev.bconst[item0 + tid] : 0.0;
+        preb = (tid < NI && item0 + tid < I) ? ev.col_b[item0 + tid] : 0.0;
     };
 
-    T pre[PER]; double preb;
-    fetch(0, pre, preb);
+    T pre[PER]; double preb; int preid;
+    fetch(0, pre, preb, preid);
     for (int item0 = 0; item0 < I; item0 += NI) {
         __syncthreads();
 #pragma unroll
@@ -363,9 +370,9 @@ __global__ void __launch_bounds__(256, 2) score_count_kernel(EvalDev ev, const T
             const int idx = tid + 256 * p, it = idx / KQ, k = idx % KQ;
             tile[it * STR + k] = (double)pre[p];
         }
-        if (tid < NI) tile_b[tid] = preb;
+        if (tid < NI) { tile_b[tid] = preb; tile_id[tid] = preid; }
         __syncthreads();
-        if (item0 + NI < I) fetch(item0 + NI, pre, preb);
+        if (item0 + NI < I) fetch(item0 + NI, pre, preb, preid);
 #pragma unroll 1
         for (int sub = 0; sub < NI / 16; sub++) {
             const int jj = sub * 16 + col;
@@ -381,6 +388,7 @@ __global__ void __launch_bounds__(256, 2) score_count_kernel(EvalDev ev, const T
                 for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt][kc], b, acc[mt], 0, 0, 0);
             }
             const double bj = tile_b[jj];
+            const int jid = tile_id[jj];
             if (STORE) {
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++)
@@ -400,7 +408,7 @@ __global__ void __launch_bounds__(256, 2) score_count_kernel(EvalDev ev, const T
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const double s = acc[mt][r] + bj;
-                    const int ok = (int)live & (int)(j != ex[mt][r].x) & (int)(j != ex[mt][r].y);
+                    const int ok = (int)live & (int)(jid != ex[mt][r].x) & (int)(jid != ex[mt][r].y);
                     cnt[mt][r] += ok & (int)(th[mt][r].x > s);
                     if (TWO) cnt2[mt][r] += ok & (int)(th[mt][r].y > s);
                 }
@@ -461,11 +469,12 @@ __global__ void __launch_bounds__(256) score_count_l1_kernel(EvalDev ev, const T
             for (int a = 0; a < QT / 4; a++) acc[a] += fabs(qs[(qg + 4 * a) * K + k] - t);
         }
         if (j < I) {
-            const double bj = ev.bconst[j];
+            const double bj = ev.col_b[j];
+            const int jid = ev.col_item ? ev.col_item[j] : j;
 #pragma unroll
             for (int a = 0; a < QT / 4; a++) {
                 if (STORE) ev.S[(qbase + qg + 4 * a) * (int64_t)I + j] = -(bj + acc[a]);
-                else cnt[a] += (j != ex1[a] && j != ex2[a] && thr[a] > -(bj + acc[a])) ? 1 : 0;
+                else cnt[a] += (jid != ex1[a] && jid != ex2[a] && thr[a] > -(bj + acc[a])) ? 1 : 0;
             }
         }
     }
@@ -497,10 +506,15 @@ __global__ void __launch_bounds__(256) correct_clicked_kernel(DevModel m, EvalDe
     const int K1 = ev.K1, K2 = ev.K2;
     const double thr = ev.thr[w], thr2 = ev.nctx == 1 ? ev.thr2[w] : 0.0;
     int c = ev.cnt[w], c2 = ev.nctx == 1 ? ev.cnt2[w] : 0;
-    int dup = 0;  // test / validation items that are also training items
+    // columns that are not candidates: every occurrence of a clicked item and of the held-out pair
+    int excluded = 0; bool test_clicked = false, val_clicked = false;
     for (int i = 0; i < nc; i++) {
         const int e = clk[i];
-        if (e == test || e == val) { dup += (e == test) + (e == val && val != test); continue; }
+        const int mult = ev.item_mult ? ev.item_mult[e] : 1;
+        excluded += mult;
+        if (e == test) test_clicked = true;
+        if (e == val) val_clicked = true;
+        if (e == test || e == val || mult == 0) continue;   // the scoring kernel never counts the held-out pair
         double s = 0;
         if (m.model == REC_TRANSREC_L1) {
             for (int k = lane; k < K1; k += 64) s += fabs(q[k] - (double)seg0[(int64_t)e * K1 + k]);
@@ -510,18 +524,26 @@ __global__ void __launch_bounds__(256) correct_clicked_kernel(DevModel m, EvalDe
             for (int k = lane; k < K2; k += 64) s += q[K1 + k] * (double)seg1[(int64_t)e * K2 + k];
             s = group_sum<64>(s) + ev.bconst[e];
         }
-        c -= thr > s ? 1 : 0;
-        c2 -= thr2 > s ? 1 : 0;
+        c -= thr > s ? mult : 0;
+        c2 -= thr2 > s ? mult : 0;
     }
+    if (!test_clicked) excluded += ev.item_mult ? ev.item_mult[test] : 1;
+    if (!val_clicked && val != test) excluded += ev.item_mult ? ev.item_mult[val] : 1;
     if (lane == 0) {
-        const int excluded = nc + 1 + (val != test ? 1 : 0) - dup;
         if (ev.nctx == 1) {
             ev.counts[3 * (int64_t)u] = c; ev.counts[3 * (int64_t)u + 1] = c2;
         } else {
             ev.counts[3 * (int64_t)u + ctx] = c;
         }
-        if (ctx == 0) ev.counts[3 * (int64_t)u + 2] = m.I - excluded;
+        if (ctx == 0) ev.counts[3 * (int64_t)u + 2] = ev.n_cols - excluded;
     }
+}
+
+template <class T>
+__global__ void gather_rows_kernel(const T* __restrict__ src, const int32_t* __restrict__ ids, int64_t n, int K, T* __restrict__ dst)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * K; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = src[(int64_t)ids[i / K] * K + i % K];
 }
 
 __global__ void fill_f64_kernel(double* p, int64_t n, double v)
@@ -543,14 +565,12 @@ __global__ void query_items_kernel(DevModel m, EvalDev ev, int32_t* qtest, int32
 }
 
 template <class T, bool TWO, bool STORE>
-static int launch_score(const EvalDev& ev, const DevModel& m, const int32_t* qtest, const int32_t* qval, hipStream_t st)
+static int launch_score(const EvalDev& ev, const T* s0, const T* s1, int n_cols, const int32_t* qtest, const int32_t* qval, hipStream_t st)
 {
-    const T* s0 = ev.seg0 >= 0 ? (const T*)m.tab[ev.seg0] : nullptr;
-    const T* s1 = ev.seg1 >= 0 ? (const T*)m.tab[ev.seg1] : nullptr;
 #define SCORE_CASE(KQv)                                                                                         \
     case KQv: {                                                                                                 \
         const unsigned blocks = (unsigned)(ev.nq_pad / (4 * TileShape<KQv>::MT * 16));                          \
-        hipLaunchKernelGGL((score_count_kernel<T, KQv, TWO, STORE>), dim3(blocks), dim3(256), 0, st, ev, s0, s1, qtest, qval, m.I); \
+        hipLaunchKernelGGL((score_count_kernel<T, KQv, TWO, STORE>), dim3(blocks), dim3(256), 0, st, ev, s0, s1, qtest, qval, n_cols); \
         break;                                                                                                  \
     }
     switch (ev.KQ) {
@@ -566,10 +586,12 @@ static unsigned blocks_for_waves(int64_t waves) { return (unsigned)((waves * 64 
 
 template <class T>
 static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host, hipStream_t st, double* score_ms,
-                     int64_t* score_launches, bool profile)
+                     int64_t* score_launches, bool profile, const int32_t* subset_host, int n_subset)
 {
     EvalDev ev = {};
     const int U = m.U, I = m.I;
+    const int NC = n_subset > 0 ? n_subset : I;   // scored columns
+    ev.n_cols = NC;
     ev.nctx = (m.model == REC_BPRMF || m.model == REC_MP) ? 1 : 2;
     ev.seg0 = ev.seg1 = -1; ev.K1 = ev.K2 = 0;
     switch (m.model) {
@@ -625,6 +647,36 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
     hipLaunchKernelGGL(item_consts_kernel<T>, dim3(blocks_for_waves(I)), dim3(256), 0, st, m, ev);
     hipLaunchKernelGGL(build_queries_kernel<T>, dim3(blocks_for_waves(ev.nq)), dim3(256), 0, st, m, ev);
     EV_TRY(hipGetLastError());
+    ev.col_b = ev.bconst;
+    const T* seg0_cols = ev.seg0 >= 0 ? (const T*)m.tab[ev.seg0] : nullptr;
+    const T* seg1_cols = ev.seg1 >= 0 ? (const T*)m.tab[ev.seg1] : nullptr;
+    if (n_subset > 0) {
+        // the sampled columns as compact tables: rows of the item segments and b gathered by item id
+        std::vector<int32_t> mult(I, 0);
+        for (int i = 0; i < n_subset; i++) {
+            if (subset_host[i] < 0 || subset_host[i] >= I) { rec_set_error("sampled item out of range"); release(); return -1; }
+            mult[subset_host[i]]++;
+        }
+        int32_t *d_ids = nullptr, *d_mult = nullptr; double* d_b = nullptr;
+        EV_TRY(alloc((void**)&d_ids, sizeof(int32_t) * n_subset));
+        EV_TRY(alloc((void**)&d_mult, sizeof(int32_t) * I));
+        EV_TRY(alloc((void**)&d_b, sizeof(double) * n_subset));
+        EV_TRY(hipMemcpyAsync(d_ids, subset_host, sizeof(int32_t) * n_subset, hipMemcpyHostToDevice, st));
+        EV_TRY(hipMemcpyAsync(d_mult, mult.data(), sizeof(int32_t) * I, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(gather_rows_kernel<double>, dim3(64), dim3(256), 0, st, (const double*)ev.bconst, (const int32_t*)d_ids, (int64_t)n_subset, 1, d_b);
+        if (seg0_cols) {
+            T* g = nullptr; EV_TRY(alloc((void**)&g, sizeof(T) * (size_t)n_subset * ev.K1));
+            hipLaunchKernelGGL(gather_rows_kernel<T>, dim3(256), dim3(256), 0, st, seg0_cols, (const int32_t*)d_ids, (int64_t)n_subset, ev.K1, g);
+            seg0_cols = g;
+        }
+        if (seg1_cols) {
+            T* g = nullptr; EV_TRY(alloc((void**)&g, sizeof(T) * (size_t)n_subset * ev.K2));
+            hipLaunchKernelGGL(gather_rows_kernel<T>, dim3(256), dim3(256), 0, st, seg1_cols, (const int32_t*)d_ids, (int64_t)n_subset, ev.K2, g);
+            seg1_cols = g;
+        }
+        EV_TRY(hipStreamSynchronize(st));   // mult (host vector) has been copied
+        ev.col_item = d_ids; ev.item_mult = d_mult; ev.col_b = d_b;
+    }
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (profile) { EV_TRY(hipEventCreate(&e0)); EV_TRY(hipEventCreate(&e1)); EV_TRY(hipEventRecord(e0, st)); }
@@ -632,10 +684,11 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
     if (l1) {
         const size_t lds_bytes = sizeof(double) * ((size_t)64 * (m.K | 1) + (size_t)L1_QT * m.K);
         hipLaunchKernelGGL((score_count_l1_kernel<T, L1_QT, false>), dim3((unsigned)(ev.nq_pad / L1_QT)), dim3(256), lds_bytes, st, ev,
-                           (const T*)m.tab[TR_H], qtest, qval, I, m.K);
+                           seg0_cols, qtest, qval, NC, m.K);
         if (hipGetLastError() != hipSuccess) { rec_set_error("launch of the L1 scoring kernel failed"); rc = -2; }
     } else {
-        rc = ev.nctx == 1 ? launch_score<T, true, false>(ev, m, qtest, qval, st) : launch_score<T, false, false>(ev, m, qtest, qval, st);
+        rc = ev.nctx == 1 ? launch_score<T, true, false>(ev, seg0_cols, seg1_cols, NC, qtest, qval, st)
+                          : launch_score<T, false, false>(ev, seg0_cols, seg1_cols, NC, qtest, qval, st);
     }
     if (rc) { release(); return rc; }
     if (profile) EV_TRY(hipEventRecord(e1, st));
@@ -794,7 +847,7 @@ static int topk_impl(const DevModel& m0, const int32_t* users_host, int n_users,
     TK_TRY(alloc((void**)&qval, sizeof(int32_t) * max_rows));
     TK_TRY(alloc((void**)&d_items, sizeof(int32_t) * (size_t)max_rows * k));
     TK_TRY(alloc((void**)&d_scores, sizeof(double) * (size_t)max_rows * k));
-    ev.cnt2 = ev.cnt; ev.counts = nullptr;
+    ev.cnt2 = ev.cnt; ev.counts = nullptr; ev.col_b = ev.bconst; ev.n_cols = I;
     hipLaunchKernelGGL(item_consts_kernel<T>, dim3(blocks_for_waves(I)), dim3(256), 0, st, m, ev);
     for (int u0 = 0; u0 < n_users; u0 += batch_users) {
         const int nu = std::min(batch_users, n_users - u0);
@@ -810,7 +863,7 @@ static int topk_impl(const DevModel& m0, const int32_t* users_host, int n_users,
             hipLaunchKernelGGL((score_count_l1_kernel<T, L1_QT, true>), dim3((unsigned)(ev.nq_pad / L1_QT)), dim3(256), lds_bytes, st, ev,
                                (const T*)m.tab[TR_H], qtest, qval, I, m.K);
         } else {
-            rc = launch_score<T, false, true>(ev, m, qtest, qval, st);
+            rc = launch_score<T, false, true>(ev, ev.seg0 >= 0 ? (const T*)m.tab[ev.seg0] : nullptr, ev.seg1 >= 0 ? (const T*)m.tab[ev.seg1] : nullptr, I, qtest, qval, st);
         }
         if (rc) { release(); return rc; }
         hipLaunchKernelGGL(topk_mask_kernel, dim3(blocks_for_waves(ev.nq)), dim3(256), 0, st, m, ev);
@@ -833,8 +886,8 @@ int eval_topk(const DevModel& m, int precision, const int32_t* users_host, int n
 }
 
 int eval_run(const DevModel& m, int precision, int32_t* counts_host, double* xpos_host, hipStream_t st, double* score_ms,
-             int64_t* score_launches, bool profile)
+             int64_t* score_launches, bool profile, const int32_t* subset_host, int n_subset)
 {
-    return precision == REC_F64 ? eval_impl<double>(m, counts_host, xpos_host, st, score_ms, score_launches, profile)
-                                : eval_impl<float>(m, counts_host, xpos_host, st, score_ms, score_launches, profile);
+    return precision == REC_F64 ? eval_impl<double>(m, counts_host, xpos_host, st, score_ms, score_launches, profile, subset_host, n_subset)
+                                : eval_impl<float>(m, counts_host, xpos_host, st, score_ms, score_launches, profile, subset_host, n_subset);
 }

@@ -30,6 +30,7 @@ public:
     int num_pos_events;
 
     virtual void sampleAUC(double* AUC_val, double* AUC_test, double* var);
+    uint64_t validation_calls = 0;  // seeds the item draw of sampleAUC
     virtual void AUC(double* AUC_val, double* AUC_test, double* HIT_val, double* HIT_test, double* MRR_val, double* MRR_test, double* var);
     virtual void copyBestModel();
     virtual void saveModel(const char* path);

@@ -142,6 +142,41 @@ def test_topk_toy_all_models_and_short_lists(model):
     e.close()
 
 
+@pytest.mark.parametrize("model", EVAL_MODELS)
+def test_sampled_eval_counts_match_oracle_on_the_same_draws(model):
+    """rec_eval_sampled (the sampleAUC estimator on the device): for the item draws it reports, the per-user
+    counts must be what model.cpp:119-140 computes on those draws - skipped when clicked / held out, not replaced."""
+    g, model, co, ci, labels = fixture_case(model, "toy")
+    e = make_engine(g, model, co, ci, labels, F64)
+    W = g["W1"] if model != "MP" else None
+    if W is not None:
+        e.upload(W)
+    o = make_oracle(g, model, co, ci, labels)
+    m, counts, sampled = e.eval_sampled(n_sampled=150, seed=9)
+    assert len(sampled) == 150 and sampled.min() >= 0 and sampled.max() < int(g["n_items"])
+    full = np.asarray(g["counts"])
+    n_ok = 0
+    for u in range(len(full)):
+        if full[u, 2] < 0:
+            assert (counts[u] == -1).all()
+            continue
+        rows = [o.score_row(W, u, 0), o.score_row(W, u, 1)]
+        pos = [int(o.val_item[u]), int(o.test_item[u])]
+        cand = [j for j in sampled.tolist() if np.isfinite(rows[0][j]) and j not in pos]
+        if not cand:
+            assert (counts[u] == -1).all()
+            continue
+        want = [sum(1 for j in cand if rows[c][pos[c]] > rows[c][j]) for c in (0, 1)]
+        assert counts[u].tolist() == [want[0], want[1], len(cand)], (model, u)
+        n_ok += 1
+    assert n_ok > 10 and int(m.n_users) == n_ok
+    # the estimator is unbiased for the mean: 40 draws of 150 against the exact value
+    exact = e.eval()[0]
+    est = np.mean([e.eval_sampled(150, seed=s)[0].auc_test for s in range(40)])
+    assert abs(est - exact.auc_test) < 0.03, (est, exact.auc_test)
+    e.close()
+
+
 @pytest.mark.parametrize("tag", ["BPRMF", "TransRec", "REBUS_mc2_L3"])
 def test_eval_f32_storage_matches_oracle_on_same_values(tag):
     """f32 tables are scored in f64 after an exact widening, so the oracle fed the rounded values must agree."""
