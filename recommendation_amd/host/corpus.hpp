@@ -26,4 +26,6 @@ public:
 
 private:
     void loadClicks(const char* clickFile, int userMin, int itemMin);
+    bool loadCache(const std::string& path);
+    void saveCache(const std::string& path) const;
 };

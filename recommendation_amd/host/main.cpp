@@ -7,10 +7,26 @@
 
 using namespace std;
 
+// With 0 iterations and an existing model file the run scores that file instead of training: the reference
+// has loadModel (src/model.cpp:195-232) but no command line that reaches it.
 template <class M>
 static void run(M& md, int iterations, const char* model_path, bool multiple_metrics)
 {
     md.init();
+    const string saved = string(model_path) + "__" + md.toString() + ".txt";
+    if (iterations == 0) {
+        if (FILE* f = fopen(saved.c_str(), "r")) {
+            fclose(f);
+            md.loadModel(saved.c_str());
+            double AUC_val, AUC_test, HIT_val, HIT_test, MRR_val, MRR_test, var;
+            md.AUC(&AUC_val, &AUC_test, &HIT_val, &HIT_test, &MRR_val, &MRR_test, &var);
+            printf("\n\n <<< %s >>> Test AUC = %f, Val AUC = %f, Test var = %f\n", md.toString().c_str(), AUC_test, AUC_val, var);
+            printf("\n\n <<< %s >>> Test HIT50 = %f, Val HIT50 = %f\n", md.toString().c_str(), HIT_test, HIT_val);
+            if (multiple_metrics) { double valid; md.MultipleMetrics(50, false, valid); }
+            md.cleanUp();
+            return;
+        }
+    }
     md.train(iterations, 0.05);
     if (multiple_metrics) { double valid; md.MultipleMetrics(50, false, valid); }
     md.saveModel((string(model_path) + "__" + md.toString() + ".txt").c_str());

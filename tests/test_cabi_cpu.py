@@ -90,3 +90,24 @@ def test_fsub_mine_tool_writes_the_file_loadpst_expects(tmp_path):
     assert r.returncode == 0
     got = [x for x in open(tmp_path / "96-FSUB" / "toy_root_fsub_minCount_1_L_1.txt").read().split("\n") if x]
     assert got == [str(i) for i in range(40)]
+
+
+def test_corpus_cache_round_trip(tmp_path):
+    """RECSYS_CORPUS_CACHE=1: the second load comes from the binary image and yields the same ids (same label file)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "recommendation_amd", "fsub_mine")
+    (tmp_path / "01-Data").mkdir(); (tmp_path / "96-FSUB").mkdir()
+    shutil.copy(os.path.join(root, "tests", "golden", "toy_clicks.txt"), tmp_path / "01-Data" / "toy.txt")
+    env = dict(os.environ, RECSYS_CORPUS_CACHE="1")
+    outs = []
+    for k in range(2):
+        r = subprocess.run([tool, "01-Data/toy.txt", "0", "0", "2", "3", f"96-FSUB/out{k}.txt"], cwd=tmp_path, env=env,
+                           capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(r.stdout)
+    assert "from cache" not in outs[0] and "Loading clicks from cache 01-Data/toy.txt.u0i0.recbin" in outs[1]
+    assert open(tmp_path / "96-FSUB" / "out0.txt").read() == open(tmp_path / "96-FSUB" / "out1.txt").read()
+    line = lambda o: [x for x in o.split("\n") if '"nUsers"' in x][0]
+    assert line(outs[0]) == line(outs[1])

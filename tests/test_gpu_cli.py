@@ -82,6 +82,14 @@ def test_bprmf_run_and_saved_model(workdir):
     _, counts = make_oracle(g, model, co, ci, labels).eval(W)
     mm = orc.metrics(counts)
     assert abs(mm[1] - auc_test) < 2e-4 and abs(mm[0] - auc_val) < 2e-4
+    # 0 iterations + the existing model file: evaluation only, criterion (b) through the command line
+    out = run(workdir, f"01-Data/{ML5}.txt", 0, 0, 1, 1, 10, 0.01, 0.01, 0, 0, 0, "03-Models/m", "BPRMF")
+    assert "loading parameters from 03-Models/m__BPR-MF__K_10_lambda_0.010000_biasReg_0.010000.txt" in out
+    assert "Iter: " not in out and "Model saved" not in out
+    m = re.search(r"Test AUC = ([0-9.]+), Val AUC = ([0-9.]+)", out)
+    assert abs(float(m.group(1)) - mm[1]) < 1e-6 and abs(float(m.group(2)) - mm[0]) < 1e-6
+    m = re.search(r"Test HIT50 = ([0-9.]+), Val HIT50 = ([0-9.]+)", out)
+    assert abs(float(m.group(1)) - mm[3]) < 1e-6 and abs(float(m.group(2)) - mm[2]) < 1e-6
 
 
 @pytest.mark.gpu
