@@ -92,12 +92,15 @@ def main():
     ap.add_argument("--clicks", type=int, default=100_000_000)
     ap.add_argument("--k", type=int, default=64)
     ap.add_argument("--model", default="BPRMF")
+    ap.add_argument("--l", type=int, default=3, help="L of Fossil / REBUS")
+    ap.add_argument("--min-count", type=int, default=2, help="minCount of the REBUS label set")
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--group", type=int, default=-1, help="group_by_item: 0 off, 1 run-combining kernel only, 2 event-major sampling (chunks grouped by positive item); -1 = engine default")
     ap.add_argument("--policy", type=int, default=-1, help="update_policy: 0 exact atomics, 1 hybrid, 2 plain stores; -1 = engine default")
     ap.add_argument("--chunk", type=int, default=1 << 27)
     ap.add_argument("--overlap", type=int, default=0)
     ap.add_argument("--eval-users", type=int, default=0, help="evaluate only the first n users of each shard (0 = all)")
+    ap.add_argument("--cpu-eval-users", type=int, default=2048, help="users of the CPU evaluation baseline (0 = skip)")
     ap.add_argument("--cpu-steps", type=int, default=12_000_000, help="tuples of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -147,8 +150,15 @@ def main():
         pass
     prec = F32 if args.precision == "f32" else F64
     esz = 4 if prec == F32 else 8
-    eng = ra.Engine(args.model, I, seq_off, seq_item, test_item, val_item, K=K, lam=0.01, bias_reg=0.01,
-                    relation_reg=0.01, alpha=0.5, precision=prec, device=local_rank, user_begin=ub, user_end=ue)
+    po = pi = None
+    L = args.l
+    if args.model == "REBUS":
+        # labels mined from the training sequences (the reference reads them from a precomputed 96-FSUB file)
+        lo, li = ra.fsub_mine(I, seq_off, seq_item, L, args.min_count)
+        po, pi = ra.build_rebus_paths(I, seq_off, seq_item, val_item, lo, li)
+    eng = ra.Engine(args.model, I, seq_off, seq_item, test_item, val_item, K=K, L=L, lam=0.01, bias_reg=0.01,
+                    relation_reg=0.01, alpha=-0.6 if args.model == "REBUS" else 0.5, precision=prec, device=local_rank,
+                    user_begin=ub, user_end=ue, path_off=po, path_item=pi)
     eng.init_params(seed=2024)
     if args.policy >= 0:
         eng.set_option("update_policy", args.policy)
@@ -206,9 +216,12 @@ def main():
     value = total_triples / dt
 
     # algorithmic bytes per triple: distinct rows read once + written once (model-specific)
-    rows = {"BPRMF": 3, "MC": 3, "HRM_avg": 4, "HRM_max": 4, "TransRec": 4, "TransRec_L1": 4, "FPMC": 6, "PRME": 6}[args.model]
-    scalars = {"BPRMF": 2, "TransRec": 2, "TransRec_L1": 2}.get(args.model, 0)
-    bytes_per_triple = 2 * rows * K * esz + 2 * scalars * esz
+    mean_hist = float(seq_off[-1]) / U
+    rows = {"BPRMF": 3, "MC": 3, "HRM_avg": 4, "HRM_max": 4, "TransRec": 4, "TransRec_L1": 4, "FPMC": 6, "PRME": 6,
+            # history models: every item of the user's history (REBUS: about half of it, the distinct prefix) + pos + neg
+            "Fossil": mean_hist + 2, "FossilSimple": mean_hist + 2, "REBUS": mean_hist / 2 + 2}[args.model]
+    scalars = {"BPRMF": 2, "TransRec": 2, "TransRec_L1": 2, "Fossil": 2 + 2 * L, "FossilSimple": 4, "REBUS": 2}.get(args.model, 0)
+    bytes_per_triple = int(2 * rows * K * esz + 2 * scalars * esz)
     tuples_per_launch = my_steps * args.steps / max(upd_n, 1)
     avg_ms = upd_ms / max(upd_n, 1)
     achieved = bytes_per_triple * tuples_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -221,12 +234,22 @@ def main():
             if name.startswith("sgd_runs_kernel" if grouped else "sgd_hogwild_kernel") and "hbm_traffic_bytes_per_launch" in e and \
                     abs(e.get("tuples_per_launch", 0) - tuples_per_launch) < 0.01 * tuples_per_launch:
                 traffic = int(e["hbm_traffic_bytes_per_launch"])
-    roofline = {"bound": "hbm", "kernel": "sgd_runs_kernel" if grouped else "sgd_hogwild_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+    roofline = {"bound": "hbm", "kernel": "sgd_history_kernel" if args.model in ("Fossil", "FossilSimple", "REBUS") else "sgd_runs_kernel" if grouped else "sgd_hogwild_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "bytes_per_triple": bytes_per_triple, "tuples_per_launch": int(tuples_per_launch),
                 "avg_launch_ms": round(avg_ms, 4), "launches": int(upd_n),
                 "sampler_ms_per_launch": round(smp_ms / max(smp_n, 1), 4),
                 "tuples_drawn_over_expected": round(eng.tuples_drawn / max(1, my_steps * (args.steps + args.warmup)), 6)}
+
+    # practical ceiling: a device-to-device copy of 1 GiB (read + write counted)
+    src = torch.empty(1 << 28, dtype=torch.float32, device=dev); dst = torch.empty_like(src)
+    dst.copy_(src); torch.cuda.synchronize()
+    c0 = time.perf_counter()
+    for _ in range(5):
+        dst.copy_(src)
+    torch.cuda.synchronize()
+    roofline["measured_copy_gbs"] = round(5 * 2 * src.numel() * 4 / (time.perf_counter() - c0) / 1e9, 1)
+    del src, dst
 
     out = {"metric": "bpr_sgd_triples_per_sec", "value": round(value, 1), "unit": "triples/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -280,6 +303,21 @@ def main():
                                "sample": f"{done} consecutive updateFactors steps of one epoch on the same corpus, fp64, "
                                          f"{ct:.1f} s"}
         out["gpu_over_cpu"] = round(value / (done / ct), 1)
+
+    # CPU baseline of the evaluation: the restatement of model::AUC on a user sample, all host cores (OpenMP over users)
+    if rank == 0 and world == 1 and args.cpu_eval_users > 0 and "eval" in out and args.model == "BPRMF":
+        from oracle import oracle_py as orc
+        sample = np.linspace(0, U - 1, args.cpu_eval_users).astype(np.int64)
+        t_s = np.full(U, -1, np.int32); t_s[sample] = test_item[sample]
+        o = orc.Oracle("BPRMF", U, I, K, seq_off, seq_item, t_s, val_item, lam=0.01, bias_reg=0.01)
+        W = eng.download()
+        cores = min(16, os.cpu_count() or 1)
+        t0 = time.perf_counter()
+        o.eval(W, nthreads=cores)
+        ct = time.perf_counter() - t0
+        out["eval"]["cpu_baseline"] = {"value": round(len(sample) / ct, 2), "unit": "users/s", "cores": cores, "kind": "port",
+                                       "sample": f"{len(sample)} evenly spaced users, full catalog, fp64, {ct:.1f} s"}
+        out["eval"]["gpu_over_cpu"] = round(out["eval"]["users_per_sec"] / (len(sample) / ct), 1)
 
     if rank == 0:
         print(json.dumps(out), flush=True)

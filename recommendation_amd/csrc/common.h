@@ -69,7 +69,9 @@ int launch_sgd_sequential(const DevModel& m, int precision, const int4* tuples, 
 int launch_sgd_hogwild(const DevModel& m, int precision, const int4* tuples, int64_t n, double lr, int atomic,
                        hipStream_t st);
 int launch_apply_global(const DevModel& m, int precision, double lr, int64_t n_tuples, double cap, hipStream_t st);
-int launch_sgd_history(const DevModel& m, int precision, const int4* tuples, int64_t n, double lr, int atomic, hipStream_t st);
+// max_in_flight: upper bound on the tuples being worked on at the same time (0 = as many as the chip holds)
+int launch_sgd_history(const DevModel& m, int precision, const int4* tuples, int64_t n, double lr, int atomic, int64_t max_in_flight,
+                       hipStream_t st);
 int launch_apply_global_history(const DevModel& m, int precision, double lr, double cap, hipStream_t st);
 int launch_sampler(const DevModel& m, int4* tuples, int64_t n, int64_t first_step, uint64_t seed, uint64_t epoch,
                    hipStream_t st);

@@ -3,7 +3,7 @@
 //
 // A tuple reads every item row of the user's history (Fossil: the whole training sequence with
 // repeats, Fossil.cpp:140-153; REBUS: the distinct items of the prefix, REBUS.cpp:305-318) twice:
-// pass 1 streams the rows into the two history sums (four rows in flight per wave), pass 2 re-reads
+// pass 1 streams the rows into the two history sums (eight rows in flight per wave at K <= 64), pass 2 re-reads
 // each row (an L2 / Infinity Cache hit) for its own regulariser term and scatters its delta with
 // float atomics.  The rows of the CSR are consecutive in seq_item, so the item ids themselves are
 // read as coalesced runs.
@@ -29,6 +29,7 @@ template <class T> __device__ __forceinline__ T wsum(T v) { return group_sum<64>
 template <int MODEL, class T, int EPL>
 __global__ void __launch_bounds__(256) sgd_history_kernel(DevModel m, const int4* __restrict__ tuples, int64_t n, T lr, int atomic)
 {
+    constexpr int RIF = EPL == 1 ? 8 : 4;   // history rows in flight per wavefront
     const int lane = threadIdx.x & 63;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -65,16 +66,16 @@ __global__ void __launch_bounds__(256) sgd_history_kernel(DevModel m, const int4
             }
             // pass 1: history sums, Fossil.cpp:140-153
             int cp = 0, cn = 0;
-            for (int h0 = 0; h0 < nu; h0 += 4) {
-                int it[4]; T x[4][EPL];
+            for (int h0 = 0; h0 < nu; h0 += RIF) {
+                int it[RIF]; T x[RIF][EPL];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < RIF; q++) {
                     it[q] = h0 + q < nu ? seq[h0 + q] : -1;
 #pragma unroll
                     for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; x[q][j] = (it[q] >= 0 && k < K) ? Ui[(int64_t)it[q] * K + k] : (T)0; }
                 }
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < RIF; q++) {
                     if (it[q] < 0) continue;
                     if (it[q] != pos) cp++;
                     if (it[q] != neg) cn++;
@@ -137,16 +138,16 @@ __global__ void __launch_bounds__(256) sgd_history_kernel(DevModel m, const int4
                 }
             }
             // pass 2: every history row, Fossil.cpp:209-247 / FossilSimple.cpp:198-226
-            for (int h0 = 0; h0 < nu; h0 += 4) {
-                int it[4]; T x[4][EPL];
+            for (int h0 = 0; h0 < nu; h0 += RIF) {
+                int it[RIF]; T x[RIF][EPL];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < RIF; q++) {
                     it[q] = h0 + q < nu ? seq[h0 + q] : -1;
 #pragma unroll
                     for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; x[q][j] = (it[q] >= 0 && k < K) ? Ui[(int64_t)it[q] * K + k] : (T)0; }
                 }
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < RIF; q++) {
                     if (it[q] < 0) continue;
                     const int c = it[q];
                     T a = 0; bool inprev = false;
@@ -197,16 +198,16 @@ __global__ void __launch_bounds__(256) sgd_history_kernel(DevModel m, const int4
                 pp[j] = k < K ? P[(int64_t)pos * K + k] : (T)0; pn[j] = k < K ? P[(int64_t)neg * K + k] : (T)0;
             }
             int cp = 0, cn = 0; bool pos_in = false, neg_in = false;
-            for (int h0 = 0; h0 < tpos; h0 += 4) {
-                int it[4]; T x[4][EPL];
+            for (int h0 = 0; h0 < tpos; h0 += RIF) {
+                int it[RIF]; T x[RIF][EPL];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < RIF; q++) {
                     it[q] = (h0 + q < tpos && fo[h0 + q]) ? seq[h0 + q] : -1;
 #pragma unroll
                     for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; x[q][j] = (it[q] >= 0 && k < K) ? P[(int64_t)it[q] * K + k] : (T)0; }
                 }
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < RIF; q++) {
                     if (it[q] < 0) continue;
                     if (it[q] != pos) cp++; else pos_in = true;
                     if (it[q] != neg) cn++; else neg_in = true;
@@ -239,16 +240,16 @@ __global__ void __launch_bounds__(256) sgd_history_kernel(DevModel m, const int4
                 scat(beta + pos, lr * (-deri - breg * bpos), bpos, at_bias && !m.hot[pos]);   // [9]
                 scat(beta + neg, lr * (deri - breg * bneg), bneg, at_bias && !m.hot[neg]);    // [10]
             }
-            for (int h0 = 0; h0 < tpos; h0 += 4) {
-                int it[4]; T x[4][EPL];
+            for (int h0 = 0; h0 < tpos; h0 += RIF) {
+                int it[RIF]; T x[RIF][EPL];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < RIF; q++) {
                     it[q] = (h0 + q < tpos && fo[h0 + q]) ? seq[h0 + q] : -1;
 #pragma unroll
                     for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; x[q][j] = (it[q] >= 0 && k < K) ? P[(int64_t)it[q] * K + k] : (T)0; }
                 }
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < RIF; q++) {
                     if (it[q] < 0) continue;
                     const int c = it[q];
                     bool inpath = false; T se = 0;
@@ -317,9 +318,12 @@ __global__ void apply_global_history_kernel(DevModel m, T lr, T cap)
 }
 
 template <int MODEL, class T>
-static int launch_history(const DevModel& m, const int4* tuples, int64_t n, double lr, int atomic, hipStream_t st)
+static int launch_history(const DevModel& m, const int4* tuples, int64_t n, double lr, int atomic, int64_t max_in_flight, hipStream_t st)
 {
-    int64_t blocks = (n + 3) / 4;
+    // one tuple per wavefront at a time: the number of wavefronts launched is the number of tuples in flight
+    int64_t waves = n;
+    if (max_in_flight > 0 && waves > max_in_flight) waves = max_in_flight;
+    int64_t blocks = (waves + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     const dim3 grid((unsigned)blocks), block(256);
     if (m.K <= 64) hipLaunchKernelGGL((sgd_history_kernel<MODEL, T, 1>), grid, block, 0, st, m, tuples, n, (T)lr, atomic);
@@ -330,21 +334,22 @@ static int launch_history(const DevModel& m, const int4* tuples, int64_t n, doub
 }
 
 template <class T>
-static int dispatch_history(const DevModel& m, const int4* tuples, int64_t n, double lr, int atomic, hipStream_t st)
+static int dispatch_history(const DevModel& m, const int4* tuples, int64_t n, double lr, int atomic, int64_t max_in_flight, hipStream_t st)
 {
     switch (m.model) {
-    case REC_FOSSIL: return launch_history<REC_FOSSIL, T>(m, tuples, n, lr, atomic, st);
-    case REC_FOSSIL_SIMPLE: return launch_history<REC_FOSSIL_SIMPLE, T>(m, tuples, n, lr, atomic, st);
-    case REC_REBUS: return launch_history<REC_REBUS, T>(m, tuples, n, lr, atomic, st);
+    case REC_FOSSIL: return launch_history<REC_FOSSIL, T>(m, tuples, n, lr, atomic, max_in_flight, st);
+    case REC_FOSSIL_SIMPLE: return launch_history<REC_FOSSIL_SIMPLE, T>(m, tuples, n, lr, atomic, max_in_flight, st);
+    case REC_REBUS: return launch_history<REC_REBUS, T>(m, tuples, n, lr, atomic, max_in_flight, st);
     default: rec_set_error("not a history model"); return -1;
     }
 }
 
-int launch_sgd_history(const DevModel& m, int precision, const int4* tuples, int64_t n, double lr, int atomic, hipStream_t st)
+int launch_sgd_history(const DevModel& m, int precision, const int4* tuples, int64_t n, double lr, int atomic, int64_t max_in_flight,
+                       hipStream_t st)
 {
     if (n <= 0) return 0;
-    return precision == REC_F64 ? dispatch_history<double>(m, tuples, n, lr, atomic, st)
-                                : dispatch_history<float>(m, tuples, n, lr, atomic, st);
+    return precision == REC_F64 ? dispatch_history<double>(m, tuples, n, lr, atomic, max_in_flight, st)
+                                : dispatch_history<float>(m, tuples, n, lr, atomic, max_in_flight, st);
 }
 
 int launch_apply_global_history(const DevModel& m, int precision, double lr, double cap, hipStream_t st)

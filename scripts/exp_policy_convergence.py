@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--every", type=int, default=5)
     ap.add_argument("--model", default="BPRMF")
     ap.add_argument("--lr", type=float, default=0.05)
+    ap.add_argument("--l", type=int, default=3)
     ap.add_argument("--chunk", type=int, default=1 << 22)
     ap.add_argument("--variants", default="0:0,1:0,1:2,2:0")
     args = ap.parse_args()
@@ -31,12 +32,23 @@ def main():
     seq_off, seq_item, test, val, _ = make_synthetic(args.users, args.items, args.clicks, 7, torch.device("cuda:0"))
     for var in args.variants.split(","):
         mask = None
+        stale = None
+        if var.startswith("s"):   # s<n>: default policy with stale_window n
+            stale, var = int(var[1:]), "-1:0"
         if var.startswith("m"):   # m<hexmask>: hybrid policy's hot exemption with this atomic mask
             mask, var = int(var[1:], 16), "1:0"
         policy, group, *rest = (int(x) for x in var.split(":"))
-        eng = ra.Engine(args.model, args.items, seq_off, seq_item, test, val, K=args.k, lam=0.01, bias_reg=0.01, alpha=0.5, precision=F32)
-        eng.set_option("update_policy", policy)
+        po = pi = None
+        if args.model == "REBUS":
+            lo, li = ra.fsub_mine(args.items, seq_off, seq_item, args.l, 2)
+            po, pi = ra.build_rebus_paths(args.items, seq_off, seq_item, val, lo, li)
+        eng = ra.Engine(args.model, args.items, seq_off, seq_item, test, val, K=args.k, L=args.l, lam=0.01, bias_reg=0.01,
+                        alpha=-0.6 if args.model == "REBUS" else 0.5, precision=F32, path_off=po, path_item=pi)
+        if policy >= 0:
+            eng.set_option("update_policy", policy)
         eng.set_option("group_by_item", group)
+        if stale is not None:
+            eng.set_option("stale_window", stale)
         if mask is not None:
             eng.set_option("atomic", mask)
         eng.set_option("chunk", args.chunk)
@@ -57,7 +69,7 @@ def main():
         um, un = eng.kernel_stats(0)
         sm, sn = eng.kernel_stats(2)
         W = eng.download()
-        print(f"policy {policy} group {group} {rest} mask {mask}: " + " | ".join(line) + f"  finite={np.isfinite(W).all()} |W|max={np.abs(W).max():.2f} "
+        print(f"policy {policy} group {group} {rest} mask {mask} stale {stale}: " + " | ".join(line) + f"  finite={np.isfinite(W).all()} |W|max={np.abs(W).max():.2f} "
               f"{t_train:.2f}s update {um / max(un, 1):.3f} ms x {un} sampler {sm / max(sn, 1):.3f} ms x {sn}", flush=True)
         eng.close()
 

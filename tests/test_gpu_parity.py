@@ -384,7 +384,7 @@ def test_history_hogwild_single_tuples(model):
             assert err < 1e-9, (model, t, err)
         else:
             n_alias += 1
-            assert err < 2e-3, (model, t, err)
+            assert err < 3e-3, (model, t, err)   # eight history rows are in flight: a repeated item is read before its first update
     assert n_clean >= 10 and (n_alias >= 1 or model == "REBUS")
     e.close()
 
