@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=1 << 27)
     ap.add_argument("--overlap", type=int, default=0)
     ap.add_argument("--eval-users", type=int, default=0, help="evaluate only the first n users of each shard (0 = all)")
-    ap.add_argument("--cpu-eval-users", type=int, default=2048, help="users of the CPU evaluation baseline (0 = skip)")
+    ap.add_argument("--cpu-eval-users", type=int, default=16384, help="users of the CPU evaluation baseline (0 = skip)")
     ap.add_argument("--cpu-steps", type=int, default=12_000_000, help="tuples of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-eval", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],

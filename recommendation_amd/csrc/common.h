@@ -27,6 +27,7 @@ struct DevModel {
     const double* eta;                  // (L+1) x L damping weights
     const int32_t* elig;                // users (MC: source items) the sampler may draw
     int n_elig;
+    int elig_identity;                  // 1: elig[i] == i for every i
     const int64_t* succ_off;            // MC: successors of each item with multiplicity ...
     const int32_t* succ_item;
     const int64_t* sset_off;            // ... and as sorted distinct sets

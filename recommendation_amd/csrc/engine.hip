@@ -269,6 +269,8 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     }
 #undef UP
     m.n_elig = (int)elig.size(); m.n_eval = (int)eval_users.size(); m.n_ev = (int64_t)ev.size();
+    m.elig_identity = 1;
+    for (size_t i = 0; i < elig.size() && m.elig_identity; i++) if (elig[i] != (int32_t)i) m.elig_identity = 0;
     auto fail = [&](int code) { rec_destroy(e); return code; };
     if (rc) return fail(rc);
     if (hipStreamCreate(&e->st) != hipSuccess || hipStreamCreate(&e->st2) != hipSuccess) { rec_set_error("hipStreamCreate failed"); return fail(-2); }

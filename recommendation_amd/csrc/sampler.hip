@@ -31,7 +31,8 @@ __global__ void __launch_bounds__(256) sampler_kernel(DevModel m, int4* __restri
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Rng rng(seed, epoch, (uint64_t)(first_step + i));
-    const int e = m.elig[bounded(rng.next(), (uint32_t)m.n_elig)];
+    const int pick = (int)bounded(rng.next(), (uint32_t)m.n_elig);
+    const int e = m.elig_identity ? pick : m.elig[pick];   // every owner eligible: the list is 0..n-1
     int4 t = make_int4(e, 0, 0, 0);
     if constexpr (MODEL == REC_MC) {
         // MC.cpp:80-89, 139-147: source item with successors, a successor, a non-successor
@@ -44,12 +45,17 @@ __global__ void __launch_bounds__(256) sampler_kernel(DevModel m, int4* __restri
     } else {
         const int64_t so = m.seq_off[e]; const int nu = (int)(m.seq_off[e + 1] - so);
         const int32_t* seq = m.seq_item + so;
-        const int32_t* clk = m.clk_item + m.clk_off[e]; const int nc = (int)(m.clk_off[e + 1] - m.clk_off[e]);
+        // the clicked list is only consulted when the filter cannot rule the candidate out
+        auto clicked = [&](int item) {
+            if (!filter_may_contain(m.neg_filter, e, item)) return false;
+            const int64_t c0 = m.clk_off[e];
+            return sorted_contains(m.clk_item + c0, (int)(m.clk_off[e + 1] - c0), item);
+        };
         if constexpr (MODEL == REC_BPRMF) {
             // BPRMF.cpp:74-83, 135-143
             const int pos = seq[bounded(rng.next(), (uint32_t)nu)];
             int neg = 0;
-            for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (!filter_may_contain(m.neg_filter, e, neg) || !sorted_contains(clk, nc, neg)) break; }
+            for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (!clicked(neg)) break; }
             t = make_int4(e, pos, neg, 0);
         } else if constexpr (MODEL == REC_FPMC || MODEL == REC_PRME || MODEL == REC_FOSSIL_SIMPLE || MODEL == REC_HRM_AVG ||
                              MODEL == REC_HRM_MAX) {
@@ -66,7 +72,7 @@ __global__ void __launch_bounds__(256) sampler_kernel(DevModel m, int4* __restri
             // TransRec.cpp:188-199
             const int p = (int)bounded(rng.next(), (uint32_t)(nu - 1));
             int neg = 0;
-            for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (!filter_may_contain(m.neg_filter, e, neg) || !sorted_contains(clk, nc, neg)) break; }
+            for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (!clicked(neg)) break; }
             t = make_int4(e, seq[p], seq[p + 1], neg);
         } else if constexpr (MODEL == REC_FOSSIL) {
             // Fossil.cpp:282-293: target position 1..nu-1, negative outside {pos} + the <= L previous items
