@@ -435,57 +435,75 @@ __global__ void __launch_bounds__(256, 2) score_count_kernel(EvalDev ev, const T
 // queries for the whole item sweep; items are staged through LDS in tiles of 64 (odd row stride:
 // conflict-free when the 64 lanes of a wavefront read 64 different items), thread (item jj, query
 // group qg) accumulates QT/4 distances per tile.
-template <class T, int QT, bool STORE>
+template <class T, int QT, int TI, bool STORE>
 __global__ void __launch_bounds__(256) score_count_l1_kernel(EvalDev ev, const T* __restrict__ H, const int32_t* __restrict__ qtest,
                                                              const int32_t* __restrict__ qval, int I, int K)
 {
+    constexpr int NG = 256 / TI, QPT = QT / NG;   // query groups per block, queries per thread
     extern __shared__ double lds[];
     const int STR = K | 1;
-    double* tile = lds;                 // [64][STR]
-    double* qs = lds + 64 * STR;        // [QT][K]
-    const int tid = threadIdx.x, jj = tid & 63, qg = tid >> 6;
+    double* tile = lds;                 // [TI][STR]
+    double* qs = lds + TI * STR;        // [QT][K]
+    const int tid = threadIdx.x, jj = tid % TI, qg = tid / TI;
     const int64_t qbase = (int64_t)blockIdx.x * QT;
     for (int i = tid; i < QT * K; i += 256) qs[i] = ev.Q[(qbase + i / K) * ev.KQ + i % K];
-    double thr[QT / 4]; int ex1[QT / 4], ex2[QT / 4], cnt[QT / 4];
+    double thr[QPT]; int ex1[QPT], ex2[QPT], cnt[QPT];
 #pragma unroll
-    for (int a = 0; a < QT / 4; a++) {
-        const int64_t qi = qbase + qg + 4 * a;
+    for (int a = 0; a < QPT; a++) {
+        const int64_t qi = qbase + qg + NG * a;
         thr[a] = ev.thr[qi]; ex1[a] = qtest[qi]; ex2[a] = qval[qi]; cnt[a] = 0;
     }
-    for (int item0 = 0; item0 < I; item0 += 64) {
+    for (int item0 = 0; item0 < I; item0 += TI) {
         __syncthreads();
-        for (int i = tid; i < 64 * K; i += 256) {
+        for (int i = tid; i < TI * K; i += 256) {
             const int it = i / K, k = i % K; const int64_t j = (int64_t)item0 + it;
             tile[it * STR + k] = j < I ? (double)H[j * K + k] : 0.0;
         }
         __syncthreads();
         const int j = item0 + jj;
-        double acc[QT / 4];
+        double acc[QPT];
 #pragma unroll
-        for (int a = 0; a < QT / 4; a++) acc[a] = 0;
+        for (int a = 0; a < QPT; a++) acc[a] = 0;
         for (int k = 0; k < K; k++) {
             const double t = tile[jj * STR + k];
 #pragma unroll
-            for (int a = 0; a < QT / 4; a++) acc[a] += fabs(qs[(qg + 4 * a) * K + k] - t);
+            for (int a = 0; a < QPT; a++) acc[a] += fabs(qs[(qg + NG * a) * K + k] - t);
         }
         if (j < I) {
             const double bj = ev.col_b[j];
             const int jid = ev.col_item ? ev.col_item[j] : j;
 #pragma unroll
-            for (int a = 0; a < QT / 4; a++) {
-                if (STORE) ev.S[(qbase + qg + 4 * a) * (int64_t)I + j] = -(bj + acc[a]);
+            for (int a = 0; a < QPT; a++) {
+                if (STORE) ev.S[(qbase + qg + NG * a) * (int64_t)I + j] = -(bj + acc[a]);
                 else cnt[a] += (jid != ex1[a] && jid != ex2[a] && thr[a] > -(bj + acc[a])) ? 1 : 0;
             }
         }
     }
     if (STORE) return;
 #pragma unroll
-    for (int a = 0; a < QT / 4; a++) {
+    for (int a = 0; a < QPT; a++) {
         int c = cnt[a];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-        if (jj == 0) ev.cnt[qbase + qg + 4 * a] = c;
+        for (int o = TI / 2; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if (jj == 0) ev.cnt[qbase + qg + NG * a] = c;
     }
+}
+
+// launches the L1 scorer with the item tile that fits the 160 KB of LDS: 64 items up to K = 160, 32 above
+template <class T, bool STORE>
+static int launch_score_l1(const EvalDev& ev, const T* H, const int32_t* qtest, const int32_t* qval, int n_cols, int K, hipStream_t st)
+{
+    constexpr int QT = 32;
+    const unsigned blocks = (unsigned)(ev.nq_pad / QT);
+    if (K <= 160) {
+        const size_t lds_bytes = sizeof(double) * ((size_t)64 * (K | 1) + (size_t)QT * K);
+        hipLaunchKernelGGL((score_count_l1_kernel<T, QT, 64, STORE>), dim3(blocks), dim3(256), lds_bytes, st, ev, H, qtest, qval, n_cols, K);
+    } else {
+        const size_t lds_bytes = sizeof(double) * ((size_t)32 * (K | 1) + (size_t)QT * K);
+        hipLaunchKernelGGL((score_count_l1_kernel<T, QT, 32, STORE>), dim3(blocks), dim3(256), lds_bytes, st, ev, H, qtest, qval, n_cols, K);
+    }
+    if (hipGetLastError() != hipSuccess) { rec_set_error("launch of the L1 scoring kernel failed"); return -2; }
+    return 0;
 }
 
 // Removes the clicked items from the counts and writes (count_val, count_test, max) per user.
@@ -682,10 +700,7 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
     if (profile) { EV_TRY(hipEventCreate(&e0)); EV_TRY(hipEventCreate(&e1)); EV_TRY(hipEventRecord(e0, st)); }
     int rc = 0;
     if (l1) {
-        const size_t lds_bytes = sizeof(double) * ((size_t)64 * (m.K | 1) + (size_t)L1_QT * m.K);
-        hipLaunchKernelGGL((score_count_l1_kernel<T, L1_QT, false>), dim3((unsigned)(ev.nq_pad / L1_QT)), dim3(256), lds_bytes, st, ev,
-                           seg0_cols, qtest, qval, NC, m.K);
-        if (hipGetLastError() != hipSuccess) { rec_set_error("launch of the L1 scoring kernel failed"); rc = -2; }
+        rc = launch_score_l1<T, false>(ev, seg0_cols, qtest, qval, NC, m.K, st);
     } else {
         rc = ev.nctx == 1 ? launch_score<T, true, false>(ev, seg0_cols, seg1_cols, NC, qtest, qval, st)
                           : launch_score<T, false, false>(ev, seg0_cols, seg1_cols, NC, qtest, qval, st);
@@ -859,9 +874,7 @@ static int topk_impl(const DevModel& m0, const int32_t* users_host, int n_users,
         hipLaunchKernelGGL(build_queries_kernel<T>, dim3(blocks_for_waves(ev.nq)), dim3(256), 0, st, m, ev);
         int rc = 0;
         if (l1) {
-            const size_t lds_bytes = sizeof(double) * ((size_t)64 * (m.K | 1) + (size_t)L1_QT * m.K);
-            hipLaunchKernelGGL((score_count_l1_kernel<T, L1_QT, true>), dim3((unsigned)(ev.nq_pad / L1_QT)), dim3(256), lds_bytes, st, ev,
-                               (const T*)m.tab[TR_H], qtest, qval, I, m.K);
+            rc = launch_score_l1<T, true>(ev, (const T*)m.tab[TR_H], qtest, qval, I, m.K, st);
         } else {
             rc = launch_score<T, false, true>(ev, ev.seg0 >= 0 ? (const T*)m.tab[ev.seg0] : nullptr, ev.seg1 >= 0 ? (const T*)m.tab[ev.seg1] : nullptr, I, qtest, qval, st);
         }

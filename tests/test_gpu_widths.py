@@ -1,0 +1,99 @@
+"""Every kernel shape: latent dimensions from 1 to 256 select different lane groupings (16 / 32 / 64
+lanes per tuple, 1 / 2 / 4 elements per lane) and different scoring tiles (query widths 16..256).
+Each is checked against the CPU oracle on the toy corpus with random parameters."""
+import numpy as np
+import pytest
+
+import recommendation_amd as ra
+from oracle import oracle_py as orc
+from recommendation_amd.capi import F32, F64, HOGWILD, SEQUENTIAL
+from tests.engine_util import rel_err
+from tests.golden_util import fixture_case
+
+pytestmark = pytest.mark.gpu
+
+WIDTHS = [1, 7, 16, 17, 32, 33, 64, 65, 100, 128, 129, 200, 256]
+MODELS = ["BPRMF", "MC", "FPMC", "PRME", "HRM_avg", "HRM_max", "TransRec", "TransRec_L1", "FossilSimple", "Fossil", "REBUS"]
+
+
+def _pair(model, K, prec):
+    g, model, co, ci, labels = fixture_case(model, "toy")
+    seq_off, seq_item, test, val = orc.split(co, ci)
+    I, U = int(g["n_items"]), len(co) - 1
+    po = pi = None
+    if model == "REBUS":
+        lo, li = orc.parse_labels(labels, I)
+        po, pi = ra.build_rebus_paths(I, seq_off, seq_item, val, lo, li)
+    kw = dict(L=int(g["L"]), lam=float(g["lam"]), bias_reg=float(g["bias_reg"]), relation_reg=float(g["relation_reg"]),
+              alpha=float(g["alpha"]), path_off=po, path_item=pi)
+    o = orc.Oracle(model, U, I, K, seq_off, seq_item, test, val, **kw)
+    e = ra.Engine(model, I, seq_off, seq_item, test, val, K=K, precision=prec, **kw)
+    return g, o, e
+
+
+@pytest.mark.parametrize("K", WIDTHS)
+@pytest.mark.parametrize("model", MODELS)
+def test_replay_and_eval_at_every_width(model, K):
+    if model in ("FPMC", "PRME") and 2 * K > 256:
+        pytest.skip("query width K + KK above 256 is rejected")
+    g, o, e = _pair(model, K, F64)
+    assert e.nw == o.nw
+    rng = np.random.default_rng(K)
+    W0 = rng.uniform(-0.3, 0.3, o.nw) / np.sqrt(K)
+    tuples = g["tuples"][:150]
+    ref = o.replay(W0, tuples, float(g["lr"]))
+    e.upload(W0)
+    e.sgd_replay(float(g["lr"]), tuples, SEQUENTIAL)
+    W1 = e.download()
+    assert rel_err(W1, ref, floor=1e-2) < 1e-9, (model, K, rel_err(W1, ref, floor=1e-2))
+    # full-catalog evaluation of the replayed parameters: identical counts
+    m, counts, xpos = e.eval(want_xpos=True)
+    ref_x, ref_c = o.eval(W1)
+    assert np.array_equal(counts, ref_c), (model, K)
+    assert np.allclose(xpos, ref_x, rtol=1e-10, atol=1e-12)
+    # one Hogwild launch on single tuples equals the in-order step (no aliasing inside one tuple except as documented)
+    e.upload(W0)
+    e.set_option("update_policy", 0)
+    # a tuple whose rows are all different (the fixtures start with deliberately aliased ones)
+    first = next(t for t in tuples if len(set(t[1:].tolist())) == 3 or model in ("BPRMF", "MC", "Fossil", "REBUS"))[None, :]
+    e.sgd_replay(float(g["lr"]), first, HOGWILD)
+    one = o.replay(W0, first, float(g["lr"]))
+    # the parallel form computes every delta from the values at the start of the step; where the reference's in-place
+    # order lets a later line see an earlier one the two differ by O(lr) of the step itself
+    step = np.abs(one - W0).max()
+    assert np.abs(e.download() - one).max() <= 0.05 * step + 1e-12, (model, K, np.abs(e.download() - one).max(), step)
+    e.close()
+
+
+@pytest.mark.parametrize("K", [33, 100, 256])
+@pytest.mark.parametrize("model", ["BPRMF", "FPMC", "TransRec", "Fossil", "REBUS"])
+def test_f32_epochs_stay_finite_and_score_like_the_oracle(model, K):
+    if model == "FPMC" and 2 * K > 256:
+        pytest.skip("query width above 256")
+    g, o, e = _pair(model, K, F32)
+    e.init_params(5)
+    for ep in range(5):
+        e.sgd_epoch(0.05, e.steps_per_epoch, seed=3, epoch=ep)
+    e.sync()
+    W = e.download()
+    assert np.isfinite(W).all()
+    _, counts, _ = e.eval()
+    _, ref_c = o.eval(W)
+    assert np.array_equal(counts, ref_c), (model, K)
+    e.close()
+
+
+def test_limits_are_rejected_with_a_message():
+    g, model, co, ci, labels = fixture_case("BPRMF", "toy")
+    seq_off, seq_item, test, val = orc.split(co, ci)
+    I = int(g["n_items"])
+    for kw in (dict(K=0), dict(K=257)):
+        with pytest.raises(RuntimeError):
+            ra.Engine("BPRMF", I, seq_off, seq_item, test, val, **kw)
+    with pytest.raises(RuntimeError):
+        ra.Engine("Fossil", I, seq_off, seq_item, test, val, K=8, L=33)
+    with pytest.raises(RuntimeError):
+        ra.Engine("REBUS", I, seq_off, seq_item, test, val, K=8, L=3)   # no matched paths given
+    bad = seq_item.copy(); bad[0] = I
+    with pytest.raises(RuntimeError):
+        ra.Engine("BPRMF", I, seq_off, bad, test, val, K=8)
