@@ -487,3 +487,29 @@ def test_converged_auc_within_0_005_of_reference(key):
     val_auc = np.mean([g["best_auc_val"] for g in got])
     assert abs(test_auc - ref_test) <= 0.005, (key, test_auc, ref_test)
     assert abs(val_auc - ref_val) <= 0.005, (key, val_auc, ref_val)
+
+
+@pytest.mark.parametrize("model", ["BPRMF", "FPMC", "TransRec", "REBUS"])
+def test_user_shards_partition_sampling_and_evaluation(model):
+    """Engines restricted to user ranges (one per rank): they sample only their own users, and their
+    evaluation sums add up to the sums of an unrestricted engine."""
+    g, model, co, ci, labels = fixture_case(model, "toy")
+    U = len(co) - 1
+    full = make_engine(g, model, co, ci, labels, F64)
+    full.upload(g["W1"])
+    want = np.array(full.eval_sums(50))
+    got = np.zeros(8)
+    cuts = [0, U // 3, U // 3, U]       # an empty shard in the middle
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if a == b:
+            continue
+        e = make_engine(g, model, co, ci, labels, F64, user_begin=a, user_end=b)
+        e.upload(g["W1"])
+        got += np.array(e.eval_sums(50))
+        t = e.sample_tuples(2000, seed=1, epoch=0)
+        assert t[:, 0].min() >= a and t[:, 0].max() < b
+        m, counts, _ = e.eval()
+        assert (counts[:a] == -1).all() and (counts[b:] == -1).all()
+        e.close()
+    assert got[7] == want[7] and np.allclose(got, want, rtol=1e-12, atol=1e-12)
+    full.close()
