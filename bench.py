@@ -225,7 +225,7 @@ def main():
     tuples_per_launch = my_steps * args.steps / max(upd_n, 1)
     avg_ms = upd_ms / max(upd_n, 1)
     achieved = bytes_per_triple * tuples_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    # HBM traffic per launch from the committed rocprofv3 --pmc passes of this same command (profiles/README.md);
+    # HBM traffic per launch from the committed rocprofv3 --pmc passes of this same command (profiles/pmc_summary.json);
     # only quoted when the profiled launch had the same size
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
@@ -241,6 +241,13 @@ def main():
                 "sampler_ms_per_launch": round(smp_ms / max(smp_n, 1), 4),
                 "tuples_drawn_over_expected": round(eng.tuples_drawn / max(1, my_steps * (args.steps + args.warmup)), 6)}
 
+    # what actually bounds the hybrid scatter: float atomics execute at the memory side at about 1.3 TB/s chip-wide
+    atomic_rows = {"BPRMF": 2, "MC": 3, "HRM_avg": 3, "HRM_max": 3, "TransRec": 3, "TransRec_L1": 3, "FPMC": 5, "PRME": 5}.get(args.model)
+    if atomic_rows and policy == 1 and avg_ms > 0:
+        ab = atomic_rows * K * esz
+        rate = ab * tuples_per_launch / (avg_ms * 1e-3) / 1e9
+        roofline["atomic"] = {"bytes_per_triple": ab, "achieved": round(rate, 1), "peak": 1300.0, "unit": "GB/s",
+                              "frac": round(rate / 1300.0, 4)}
     # practical ceiling: a device-to-device copy of 1 GiB (read + write counted)
     src = torch.empty(1 << 28, dtype=torch.float32, device=dev); dst = torch.empty_like(src)
     dst.copy_(src); torch.cuda.synchronize()

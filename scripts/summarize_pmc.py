@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""rocprofv3 --pmc CSVs (one directory per pass, see profiles/README.md) -> one JSON with the
+"""rocprofv3 --pmc CSVs (one directory per pass) -> one JSON with the
 per-launch averages of the engine's kernels.  FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in
 KiB; they are converted to bytes here.  FETCH_SIZE under-reports wide (16 B per lane) streaming reads by
 2x on gfx950; the update kernel reads 4 B per lane, an access width for which the counter is not
