@@ -35,6 +35,9 @@ def main():
         stale = None
         if var.startswith("s"):   # s<n>: default policy with stale_window n
             stale, var = int(var[1:]), "-1:0"
+        gwin = None
+        if var.startswith("g"):   # g<n>: default policy with global_window n
+            gwin, var = int(var[1:]), "-1:0"
         if var.startswith("m"):   # m<hexmask>: hybrid policy's hot exemption with this atomic mask
             mask, var = int(var[1:], 16), "1:0"
         policy, group, *rest = (int(x) for x in var.split(":"))
@@ -49,6 +52,8 @@ def main():
         eng.set_option("group_by_item", group)
         if stale is not None:
             eng.set_option("stale_window", stale)
+        if gwin is not None:
+            eng.set_option("global_window", gwin)
         if mask is not None:
             eng.set_option("atomic", mask)
         eng.set_option("chunk", args.chunk)
@@ -69,7 +74,7 @@ def main():
         um, un = eng.kernel_stats(0)
         sm, sn = eng.kernel_stats(2)
         W = eng.download()
-        print(f"policy {policy} group {group} {rest} mask {mask} stale {stale}: " + " | ".join(line) + f"  finite={np.isfinite(W).all()} |W|max={np.abs(W).max():.2f} "
+        print(f"policy {policy} group {group} {rest} mask {mask} stale {stale} gwin {gwin}: " + " | ".join(line) + f"  finite={np.isfinite(W).all()} |W|max={np.abs(W).max():.2f} "
               f"{t_train:.2f}s update {um / max(un, 1):.3f} ms x {un} sampler {sm / max(sn, 1):.3f} ms x {sn}", flush=True)
         eng.close()
 
