@@ -525,13 +525,7 @@ static int check_tuples(const rec_engine* e, const int32_t* t, int64_t n)
         switch (model) {
         case REC_BPRMF: ok = a >= 0 && a < U && b >= 0 && b < I && c >= 0 && c < I; break;
         case REC_MC: ok = a >= 0 && a < I && b >= 0 && b < I && c >= 0 && c < I; break;
-        case REC_FOSSIL: case REC_REBUS: {
-            ok = a >= 0 && a < U && c >= 0 && c < I;
-            if (ok) {
-                // seq offsets live on the host only during rec_create; bounds are re-derived from steps via the device copy
-            }
-            break;
-        }
+        case REC_FOSSIL: case REC_REBUS: ok = a >= 0 && a < U && c >= 0 && c < I; break;   // the position b is checked by the caller
         default: ok = a >= 0 && a < U && b >= 0 && b < I && c >= 0 && c < I && d >= 0 && d < I; break;
         }
         if (!ok) { rec_set_error("tuple " + std::to_string(i) + " is out of range"); return -1; }
