@@ -150,15 +150,23 @@ def main():
         pass
     prec = F32 if args.precision == "f32" else F64
     esz = 4 if prec == F32 else 8
+    def stage(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    stage(f"corpus ready: {U} users, {I} items, {n_clicks} interactions")
     po = pi = None
     L = args.l
     if args.model == "REBUS":
         # labels mined from the training sequences (the reference reads them from a precomputed 96-FSUB file)
         lo, li = ra.fsub_mine(I, seq_off, seq_item, L, args.min_count)
+        stage(f"{len(lo) - 1} labels mined")
         po, pi = ra.build_rebus_paths(I, seq_off, seq_item, val_item, lo, li)
+        stage("matched paths built")
     eng = ra.Engine(args.model, I, seq_off, seq_item, test_item, val_item, K=K, L=L, lam=0.01, bias_reg=0.01,
                     relation_reg=0.01, alpha=-0.6 if args.model == "REBUS" else 0.5, precision=prec, device=local_rank,
                     user_begin=ub, user_end=ue, path_off=po, path_item=pi)
+    stage("engine created")
     eng.init_params(seed=2024)
     if args.policy >= 0:
         eng.set_option("update_policy", args.policy)

@@ -9,6 +9,8 @@
 #include <stdint.h>
 #include <omp.h>
 #include <string>
+#include <algorithm>
+#include <parallel/algorithm>
 #include <unordered_map>
 #include <vector>
 #include "../../include/recsys_engine.h"
@@ -16,32 +18,60 @@
 void rec_set_error(const std::string& msg);
 
 namespace {
+// Labels as a trie over item ids, newest item first.  Edges live in an open-addressing table; every node also
+// carries a 256-bit filter of the items that extend it, so that the long scans of findPathStars (which skips
+// every item that does not extend the current label and keeps going to the start of the history) reject most
+// items with one bit test.
 struct Trie {
-    std::unordered_map<uint64_t, int32_t> edge;  // (node << 32 | item) -> child node
-    std::vector<uint8_t> is_label;               // per node
+    std::unordered_map<uint64_t, int32_t> build;  // (node << 32 | item) -> child node, while inserting
+    std::vector<uint8_t> is_label;                // per node
+    std::vector<uint64_t> keys; std::vector<int32_t> vals; uint64_t mask = 0;   // frozen table
+    std::vector<uint64_t> filter;                 // [nodes][4]
     int max_len = 0;
     Trie() : is_label(1, 0) {}
+    static uint64_t mix(uint64_t k) { k *= 0x9E3779B97F4A7C15ull; return k ^ (k >> 29); }
     void insert(const int32_t* it, int len)
     {
         int32_t node = 0;
         for (int p = len - 1; p >= 0; p--) {  // newest first
             const uint64_t key = ((uint64_t)(uint32_t)node << 32) | (uint32_t)it[p];
-            auto f = edge.find(key);
-            if (f == edge.end()) {
+            auto f = build.find(key);
+            if (f == build.end()) {
                 const int32_t child = (int32_t)is_label.size();
                 is_label.push_back(0);
-                edge.emplace(key, child);
+                build.emplace(key, child);
                 node = child;
             } else node = f->second;
         }
         if (len > 0) { is_label[node] = 1; if (len > max_len) max_len = len; }
     }
+    void freeze()
+    {
+        uint64_t cap = 16;
+        while (cap < 2 * build.size() + 16) cap <<= 1;
+        mask = cap - 1;
+        keys.assign(cap, ~(uint64_t)0); vals.assign(cap, -1);
+        filter.assign(is_label.size() * 4, 0);
+        for (const auto& kv : build) {
+            if (!is_label[kv.second]) continue;   // only label nodes can ever be returned
+            uint64_t h = mix(kv.first) & mask;
+            while (keys[h] != ~(uint64_t)0) h = (h + 1) & mask;
+            keys[h] = kv.first; vals[h] = kv.second;
+            const uint32_t node = (uint32_t)(kv.first >> 32), bit = (uint32_t)mix((uint32_t)kv.first) & 255;
+            filter[(size_t)node * 4 + (bit >> 6)] |= (uint64_t)1 << (bit & 63);
+        }
+        std::unordered_map<uint64_t, int32_t>().swap(build);
+    }
     // node of "item-<sequence of node>" when that is a label, else -1
     int32_t extend(int32_t node, int32_t item) const
     {
-        auto f = edge.find(((uint64_t)(uint32_t)node << 32) | (uint32_t)item);
-        if (f == edge.end() || !is_label[f->second]) return -1;
-        return f->second;
+        const uint32_t bit = (uint32_t)mix((uint32_t)item) & 255;
+        if (!((filter[(size_t)node * 4 + (bit >> 6)] >> (bit & 63)) & 1)) return -1;
+        const uint64_t key = ((uint64_t)(uint32_t)node << 32) | (uint32_t)item;
+        for (uint64_t h = mix(key) & mask;; h = (h + 1) & mask) {
+            if (keys[h] == key) return vals[h];
+            if (keys[h] == ~(uint64_t)0) return -1;
+        }
     }
 };
 
@@ -66,6 +96,7 @@ extern "C" int64_t rec_rebus_build_paths(int32_t n_users, int32_t n_items, const
     if (!seq_off || !seq_item || !val_item || !lab_off || !path_off) { rec_set_error("null argument"); return -1; }
     Trie tr;
     for (int64_t i = 0; i < n_labels; i++) tr.insert(lab_item + lab_off[i], (int)(lab_off[i + 1] - lab_off[i]));
+    tr.freeze();
     // pass 1: lengths
     const int64_t nctx = seq_off[n_users] + 2 * (int64_t)n_users;
 #pragma omp parallel for schedule(dynamic, 256)
@@ -125,29 +156,34 @@ extern "C" int64_t rec_fsub_mine(int32_t n_users, int32_t n_items, const int64_t
         for (int64_t p = 0; p < E; p++) cur[p] = id[seq_item[p]];
     }
     for (int32_t len = 2; len <= L; len++) {
-        std::unordered_map<uint64_t, int64_t> cnt;
-        auto key_at = [&](int32_t u, int64_t p) -> int64_t {   // -1: no candidate of this length starts at p
-            if (p + len > seq_off[u + 1] || cur[p] < 0 || cur[p + 1] < 0) return -1;
-            return (int64_t)(((uint64_t)cur[p] << 32) | (uint32_t)seq_item[p + len - 1]);
-        };
         if (nodes.size() >= ((uint64_t)1 << 31)) { rec_set_error("too many labels"); return -1; }
+        // candidates of this length as (node of the length-1 prefix, next item) keys; sorted, equal keys are adjacent
+        std::vector<uint64_t> key(E);
+        const uint64_t NONE = ~(uint64_t)0;
+#pragma omp parallel for schedule(static, 4096)
         for (int32_t u = 0; u < n_users; u++)
-            for (int64_t p = seq_off[u]; p < seq_off[u + 1]; p++) { const int64_t k = key_at(u, p); if (k >= 0) cnt[(uint64_t)k]++; }
-        std::unordered_map<uint64_t, int64_t> id;
-        for (const auto& kv : cnt)
-            if (kv.second >= min_count) {
-                id[kv.first] = (int64_t)nodes.size();
-                nodes.push_back({(int64_t)(kv.first >> 32), (int32_t)(uint32_t)kv.first, len});
-            }
-        if (id.empty()) break;
-        std::fill(nxt.begin(), nxt.end(), -1);
-        for (int32_t u = 0; u < n_users; u++)
-            for (int64_t p = seq_off[u]; p < seq_off[u + 1]; p++) {
-                const int64_t k = key_at(u, p);
-                if (k < 0) continue;
-                auto it = id.find((uint64_t)k);
-                if (it != id.end()) nxt[p] = it->second;
-            }
+            for (int64_t p = seq_off[u]; p < seq_off[u + 1]; p++)
+                key[p] = (p + len > seq_off[u + 1] || cur[p] < 0 || cur[p + 1] < 0)
+                             ? NONE : (((uint64_t)cur[p] << 32) | (uint32_t)seq_item[p + len - 1]);
+        std::vector<uint64_t> sorted(key);
+        __gnu_parallel::sort(sorted.begin(), sorted.end());
+        std::vector<uint64_t> freq;   // frequent keys, ascending
+        for (int64_t i = 0; i < E && sorted[i] != NONE;) {
+            int64_t j = i + 1;
+            while (j < E && sorted[j] == sorted[i]) j++;
+            if (j - i >= min_count) freq.push_back(sorted[i]);
+            i = j;
+        }
+        if (freq.empty()) break;
+        const int64_t base = (int64_t)nodes.size();
+        for (uint64_t k : freq) nodes.push_back({(int64_t)(k >> 32), (int32_t)(uint32_t)k, len});
+#pragma omp parallel for schedule(static, 65536)
+        for (int64_t p = 0; p < E; p++) {
+            nxt[p] = -1;
+            if (key[p] == NONE) continue;
+            auto it = std::lower_bound(freq.begin(), freq.end(), key[p]);
+            if (it != freq.end() && *it == key[p]) nxt[p] = base + (it - freq.begin());
+        }
         cur.swap(nxt);
     }
     int64_t total = 0;
