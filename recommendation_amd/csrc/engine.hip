@@ -199,41 +199,6 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
             }
         }
     }
-    // sampling events ordered by positive item (launch_event_sampler): one per (owner, position) the tuple-major
-    // sampler can pick, with the owner's 1/count as weight
-    std::vector<int4> ev; std::vector<float> ev_w;
-    if (sgd_runs_supported(d->model)) {
-        const bool mc = d->model == REC_MC, bpr = d->model == REC_BPRMF;
-        auto n_events = [&](int o) -> int64_t { return mc ? succ_off[o + 1] - succ_off[o] : bpr ? seq_off[o + 1] - seq_off[o] : seq_off[o + 1] - seq_off[o] - 1; };
-        auto event_of = [&](int o, int64_t x) -> int4 {
-            if (mc) return make_int4(o, 0, succ_item[succ_off[o] + x], 0);
-            if (bpr) return make_int4(o, 0, seq_item[seq_off[o] + x], 0);
-            return make_int4(o, seq_item[seq_off[o] + x], seq_item[seq_off[o] + x + 1], 0);
-        };
-        std::vector<int64_t> start(I + 1, 0);
-        int64_t total = 0;
-        for (int o : elig) { const int64_t c = n_events(o); total += c; for (int64_t x = 0; x < c; x++) start[event_of(o, x).z + 1]++; }
-        for (int i = 0; i < I; i++) start[i + 1] += start[i];
-        ev.resize(total); ev_w.resize(total);
-        for (int o : elig) {
-            const int64_t c = n_events(o); const float w = 1.0f / (float)c;
-            for (int64_t x = 0; x < c; x++) { const int4 r = event_of(o, x); const int64_t at = start[r.z]++; ev[at] = r; ev_w[at] = w; }
-        }
-        // The events of one item are kept in random order.  In owner order every popular item would visit the
-        // users in the same sequence, and the lane groups working on different items would reach the same user
-        // at the same moment, launch after launch.
-        uint64_t x64 = 0x2545F4914F6CDD1Dull;
-        auto rnd = [&](uint64_t bound) { x64 ^= x64 << 13; x64 ^= x64 >> 7; x64 ^= x64 << 17; return (x64 >> 11) % bound; };
-        int64_t b0 = 0;
-        for (int i = 0; i < I; i++) {   // start[i] is now the end of item i's events
-            const int64_t b1 = start[i];
-            for (int64_t k = b1 - 1; k > b0; k--) {
-                const int64_t j = b0 + (int64_t)rnd((uint64_t)(k - b0 + 1));
-                std::swap(ev[k], ev[j]); std::swap(ev_w[k], ev_w[j]);
-            }
-            b0 = b1;
-        }
-    }
     for (int u = ub; u < ue; u++) if (test_item[u] >= 0) eval_users.push_back(u);
     for (int u : eval_users)
         if (seq_off[u + 1] - seq_off[u] < 1 || val_item[u] < 0 || val_item[u] >= I || test_item[u] >= I) {
@@ -257,7 +222,7 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
 #define UP(vec, field) if (!rc) rc = upload(e, vec, &m.field)
     UP(seq_off, seq_off); UP(seq_item, seq_item); UP(test_item, test_item); UP(val_item, val_item);
     UP(clk_off, clk_off); UP(clk_item, clk_item); UP(first_occ, first_occ); UP(elig, elig); UP(eval_users, eval_users);
-    UP(train_count, train_count); UP(eta, eta); UP(ev, ev); UP(ev_w, ev_w); UP(neg_filter, neg_filter);
+    UP(train_count, train_count); UP(eta, eta); UP(neg_filter, neg_filter);
     if (d->model == REC_MC) { UP(succ_off, succ_off); UP(succ_item, succ_item); UP(sset_off, sset_off); UP(sset_item, sset_item); }
     if (d->model == REC_REBUS && !rc) {
         const int64_t nctx = E + 2 * (int64_t)U;
@@ -268,7 +233,7 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
         UP(po, path_off); UP(pi, path_item);
     }
 #undef UP
-    m.n_elig = (int)elig.size(); m.n_eval = (int)eval_users.size(); m.n_ev = (int64_t)ev.size();
+    m.n_elig = (int)elig.size(); m.n_eval = (int)eval_users.size(); m.n_ev = 0;
     m.elig_identity = 1;
     for (size_t i = 0; i < elig.size() && m.elig_identity; i++) if (elig[i] != (int32_t)i) m.elig_identity = 0;
     auto fail = [&](int code) { rec_destroy(e); return code; };
@@ -287,12 +252,6 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     if (hipMalloc(&g, 8 * (REC_MAX_K + 2 * REC_MAX_L + 8)) != hipSuccess) { rec_set_error("hipMalloc failed"); return fail(-2); }
     e->owned.push_back(g); (void)hipMemset(g, 0, 8 * (REC_MAX_K + 2 * REC_MAX_L + 8));
     m.gacc = g;
-    if (m.n_ev > 0) {
-        if (hipMalloc(&e->group_scratch, event_scratch_bytes(m.n_ev)) != hipSuccess || hipMalloc((void**)&e->n_drawn_dev, 64) != hipSuccess) {
-            rec_set_error("hipMalloc failed"); return fail(-2);
-        }
-        e->owned.push_back(e->group_scratch); e->owned.push_back(e->n_drawn_dev);
-    }
     void* hot = nullptr;
     if (hipMalloc(&hot, I + 64) != hipSuccess) { rec_set_error("hipMalloc failed"); return fail(-2); }
     e->owned.push_back(hot); (void)hipMemset(hot, 0, I + 64);
@@ -472,6 +431,62 @@ static int ensure_tuples(rec_engine* e, int64_t n)
     return 0;
 }
 
+// Sampling events ordered by positive item (launch_event_sampler): one per (owner, position) the tuple-major sampler
+// can pick, with the owner's 1/count as weight.  Built on first use from the device copies of the corpus - the
+// default (tuple-major) path never needs them.
+static int ensure_events(rec_engine* e)
+{
+    if (e->dm.n_ev > 0) return 0;
+    if (!sgd_runs_supported(e->desc.model)) { rec_set_error("the event-major sampler is not available for this model"); return -1; }
+    const int I = e->I, U = e->U;
+    const bool mc = e->desc.model == REC_MC, bpr = e->desc.model == REC_BPRMF;
+    DevModel& m = e->dm;
+    std::vector<int32_t> elig(m.n_elig);
+    ENG_HIP(hipMemcpy(elig.data(), m.elig, sizeof(int32_t) * elig.size(), hipMemcpyDeviceToHost));
+    const int n_owner = mc ? I : U;
+    std::vector<int64_t> off(n_owner + 1);
+    ENG_HIP(hipMemcpy(off.data(), mc ? m.succ_off : m.seq_off, sizeof(int64_t) * off.size(), hipMemcpyDeviceToHost));
+    std::vector<int32_t> item(off[n_owner]);
+    ENG_HIP(hipMemcpy(item.data(), mc ? m.succ_item : m.seq_item, sizeof(int32_t) * item.size(), hipMemcpyDeviceToHost));
+    auto n_events = [&](int o) -> int64_t { return (mc || bpr) ? off[o + 1] - off[o] : off[o + 1] - off[o] - 1; };
+    auto event_of = [&](int o, int64_t x) -> int4 {
+        if (mc || bpr) return make_int4(o, 0, item[off[o] + x], 0);
+        return make_int4(o, item[off[o] + x], item[off[o] + x + 1], 0);
+    };
+    std::vector<int64_t> start(I + 1, 0);
+    int64_t total = 0;
+    for (int o : elig) { const int64_t c = n_events(o); total += c; for (int64_t x = 0; x < c; x++) start[event_of(o, x).z + 1]++; }
+    if (total <= 0) { rec_set_error("no sampling events"); return -1; }
+    for (int i = 0; i < I; i++) start[i + 1] += start[i];
+    std::vector<int4> ev(total); std::vector<float> ev_w(total);
+    for (int o : elig) {
+        const int64_t c = n_events(o); const float w = 1.0f / (float)c;
+        for (int64_t x = 0; x < c; x++) { const int4 r = event_of(o, x); const int64_t at = start[r.z]++; ev[at] = r; ev_w[at] = w; }
+    }
+    // The events of one item are kept in random order.  In owner order every popular item would visit the
+    // users in the same sequence, and the lane groups working on different items would reach the same user
+    // at the same moment, launch after launch.
+    uint64_t x64 = 0x2545F4914F6CDD1Dull;
+    auto rnd = [&](uint64_t bound) { x64 ^= x64 << 13; x64 ^= x64 >> 7; x64 ^= x64 << 17; return (x64 >> 11) % bound; };
+    int64_t b0 = 0;
+    for (int i = 0; i < I; i++) {   // start[i] is now the end of item i's events
+        const int64_t b1 = start[i];
+        for (int64_t k = b1 - 1; k > b0; k--) {
+            const int64_t j = b0 + (int64_t)rnd((uint64_t)(k - b0 + 1));
+            std::swap(ev[k], ev[j]); std::swap(ev_w[k], ev_w[j]);
+        }
+        b0 = b1;
+    }
+    if (int rc = upload(e, ev, &m.ev)) return rc;
+    if (int rc = upload(e, ev_w, &m.ev_w)) return rc;
+    ENG_HIP(hipMalloc(&e->group_scratch, event_scratch_bytes(total)));
+    e->owned.push_back(e->group_scratch);
+    ENG_HIP(hipMalloc((void**)&e->n_drawn_dev, 64));
+    e->owned.push_back(e->n_drawn_dev);
+    m.n_ev = total;
+    return 0;
+}
+
 // Hogwild launches over `n` tuples.  Models with a row that every tuple touches (TransRec's r,
 // Fossil's WT, FossilSimple's alpha) keep that row constant during a launch and fold its summed
 // gradient in afterwards, so their launches are kept short (`global_window` tuples).
@@ -579,7 +594,8 @@ extern "C" int rec_sgd_epoch(rec_engine* e, double lr, int64_t n_steps, uint64_t
     ENG_HIP(hipSetDevice(e->desc.device));
     const int64_t chunk = std::min(e->chunk, n_steps);
     // event-major chunks have a Poisson-distributed length: room for 8 standard deviations
-    const bool grouped = e->group >= 2 && e->dm.n_ev > 0 && (e->stale_window == 0 || e->stale_window >= chunk);
+    const bool grouped = e->group >= 2 && sgd_runs_supported(e->desc.model) && (e->stale_window == 0 || e->stale_window >= chunk);
+    if (grouped) { if (int rc = ensure_events(e)) return rc; }
     const int64_t cap = grouped ? chunk + 8 * (int64_t)std::sqrt((double)chunk) + 1024 : chunk;
     if (e->tuples_cap < cap) { if (int rc = ensure_tuples(e, cap)) return rc; }
     hipEvent_t a = nullptr, b = nullptr;
@@ -624,8 +640,8 @@ extern "C" int rec_sample_events(rec_engine* e, int64_t n_expected, uint64_t see
 {
     if (!e || !out || !n_out) { rec_set_error("null argument"); return -1; }
     if (n_expected <= 0 || cap <= 0) { rec_set_error("n_expected and cap must be positive"); return -1; }
-    if (e->dm.n_ev <= 0) { rec_set_error("the event-major sampler is not available for this model"); return -1; }
     ENG_HIP(hipSetDevice(e->desc.device));
+    if (int rc = ensure_events(e)) return rc;
     if (int rc = ensure_tuples(e, cap)) return rc;
     if (int rc = launch_event_sampler(e->dm, e->tuples, cap, n_expected, 0, 0, seed, epoch, e->group_scratch, e->n_drawn_dev, e->st)) return rc;
     int64_t drawn = 0;
