@@ -21,6 +21,7 @@
 //                      valid user: len,path (val ctx), len,path (test ctx)
 //   <out>.eta.f64      REBUS only: eta_cumWeibullSoftmax rows n=0..L flattened
 
+#include <chrono>
 #include "corpus.hpp"
 #include "MostPopular.hpp"
 #include "BPRMF.hpp"
@@ -158,12 +159,16 @@ static void finish_simple(M& md)
 }
 
 // "traj:N:C" in place of the tuples file: N epochs of the model's own oneiteration()/oneIteration(),
-// the model's own AUC() every C epochs; prints "TRAJ iter AUC_val AUC_test HIT_val HIT_test".
+// the model's own AUC() every C epochs; prints "EPOCH iter seconds" after every epoch and
+// "TRAJ iter AUC_val AUC_test HIT_val HIT_test" after every evaluation.
 static int g_traj_n = 0, g_traj_c = 0;
 #define TRAJ(md, EPOCH_CALL)                                                                  \
 	do {                                                                                      \
 		for (int it = 1; it <= g_traj_n; it++) {                                              \
+			const auto t0_ = std::chrono::steady_clock::now();                                \
 			md.EPOCH_CALL(lr);                                                                \
+			fprintf(stderr, "EPOCH %d %.6f\n", it,                                            \
+			        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count()); \
 			if (it % g_traj_c == 0) {                                                         \
 				double m[7]; md.AUC(&m[0], &m[1], &m[2], &m[3], &m[4], &m[5], &m[6]);         \
 				fprintf(stderr, "TRAJ %d %.6f %.6f %.6f %.6f\n", it, m[0], m[1], m[2], m[3]);  \
