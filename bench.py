@@ -144,6 +144,7 @@ def main():
     ap.add_argument("--policy", type=int, default=-1, help="update_policy: 0 exact atomics, 1 hybrid, 2 plain stores; -1 = engine default")
     ap.add_argument("--chunk", type=int, default=1 << 27)
     ap.add_argument("--overlap", type=int, default=0)
+    ap.add_argument("--user-batch", type=int, default=0, help="user_batch of the history models (1, 2, 4, 8); 0 = engine default")
     ap.add_argument("--eval-users", type=int, default=0, help="evaluate only the first n users of each shard (0 = all)")
     ap.add_argument("--cpu-eval-users", type=int, default=16384, help="users of the CPU evaluation baseline (0 = skip)")
     ap.add_argument("--cpu-ref-users", type=int, default=60000, help="users of the click file the reference binary is timed on (0 = skip)")
@@ -222,6 +223,8 @@ def main():
     grouped = (args.group if args.group >= 0 else 0) == 2 and args.model in ("BPRMF", "MC", "FPMC", "PRME", "HRM_avg", "HRM_max")
     eng.set_option("chunk", args.chunk)
     eng.set_option("overlap", args.overlap)
+    if args.user_batch > 0:
+        eng.set_option("user_batch", args.user_batch)
     eng.set_option("profile", 1)
     steps_per_epoch = eng.steps_per_epoch
     my_steps = steps_per_epoch // world

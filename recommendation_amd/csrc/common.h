@@ -32,6 +32,7 @@ struct DevModel {
     const int32_t* succ_item;
     const int64_t* sset_off;            // ... and as sorted distinct sets
     const int32_t* sset_item;
+    int* work_counter;                  // next unclaimed tuple group of the running history launch
     void* gacc;                         // accumulators for rows every tuple touches (TransRec r, Fossil WT, FossilSimple alpha)
     const int32_t* eval_users;          // users of this engine's shard that have a test item
     int n_eval;
@@ -70,12 +71,15 @@ int launch_sgd_sequential(const DevModel& m, int precision, const int4* tuples, 
 int launch_sgd_hogwild(const DevModel& m, int precision, const int4* tuples, int64_t n, double lr, int atomic,
                        hipStream_t st);
 int launch_apply_global(const DevModel& m, int precision, double lr, int64_t n_tuples, double cap, hipStream_t st);
-// max_in_flight: upper bound on the tuples being worked on at the same time (0 = as many as the chip holds)
+// max_in_flight: upper bound on the tuples being worked on at the same time (0 = as many as the chip holds).
+// batch (1, 2, 4, 8): the tuples come in aligned groups of `batch` consecutive tuples of one user; one wavefront
+// walks a group's shared history once.
 int launch_sgd_history(const DevModel& m, int precision, const int4* tuples, int64_t n, double lr, int atomic, int64_t max_in_flight,
-                       hipStream_t st);
+                       int batch, hipStream_t st);
 int launch_apply_global_history(const DevModel& m, int precision, double lr, double cap, hipStream_t st);
+// user_batch > 1: every aligned group of user_batch consecutive steps shares its owner (user) draw
 int launch_sampler(const DevModel& m, int4* tuples, int64_t n, int64_t first_step, uint64_t seed, uint64_t epoch,
-                   hipStream_t st);
+                   hipStream_t st, int user_batch = 1);
 int launch_convert_in(const double* src, void* dst, int64_t n, int precision, hipStream_t st);
 int launch_convert_out(const void* src, double* dst, int64_t n, int precision, hipStream_t st);
 int launch_param_init(const DevModel& m, int precision, uint64_t seed, hipStream_t st);

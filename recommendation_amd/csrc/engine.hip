@@ -46,6 +46,7 @@ struct rec_engine {
     int profile = 0;
     RunPolicy run_policy = {128, 32, 0};
     int64_t run_segment = 0;  // batches per lane group in the run-combining kernel (0 = automatic)
+    int user_batch = 1;  // consecutive steps of an epoch that share their user draw (history models)
     int group = 0;       // 1: run-combining update kernel on the tuples as they come; 2: also sample by event, which yields chunks grouped by positive item
     // hip-event statistics: 0 update, 1 score, 2 sampler, 3 unused
     double ms[4] = {0, 0, 0, 0};
@@ -252,6 +253,10 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     if (hipMalloc(&g, 8 * (REC_MAX_K + 2 * REC_MAX_L + 8)) != hipSuccess) { rec_set_error("hipMalloc failed"); return fail(-2); }
     e->owned.push_back(g); (void)hipMemset(g, 0, 8 * (REC_MAX_K + 2 * REC_MAX_L + 8));
     m.gacc = g;
+    void* wc = nullptr;
+    if (hipMalloc(&wc, 64) != hipSuccess) { rec_set_error("hipMalloc failed"); return fail(-2); }
+    e->owned.push_back(wc); (void)hipMemset(wc, 0, 64);
+    m.work_counter = (int*)wc;
     void* hot = nullptr;
     if (hipMalloc(&hot, I + 64) != hipSuccess) { rec_set_error("hipMalloc failed"); return fail(-2); }
     e->owned.push_back(hot); (void)hipMemset(hot, 0, I + 64);
@@ -490,18 +495,21 @@ static int ensure_events(rec_engine* e)
 // Hogwild launches over `n` tuples.  Models with a row that every tuple touches (TransRec's r,
 // Fossil's WT, FossilSimple's alpha) keep that row constant during a launch and fold its summed
 // gradient in afterwards, so their launches are kept short (`global_window` tuples).
-static int launch_update(rec_engine* e, const int4* tuples, int64_t n, double lr, bool grouped = false)
+static bool history_model(int model) { return model == REC_FOSSIL || model == REC_FOSSIL_SIMPLE || model == REC_REBUS; }
+
+static int launch_update(rec_engine* e, const int4* tuples, int64_t n, double lr, bool grouped = false, int user_batch = 1)
 {
     const int model = e->desc.model;
     const bool history = model == REC_FOSSIL || model == REC_FOSSIL_SIMPLE || model == REC_REBUS;
     const bool global_row = model == REC_TRANSREC || model == REC_TRANSREC_L1 || model == REC_FOSSIL || model == REC_FOSSIL_SIMPLE;
     int64_t window = global_row ? e->global_window : n;
+    if (user_batch > 1 && window > 8) window &= ~(int64_t)7;   // launches start on a group boundary
     // Small catalogs: the history kernel bounds the tuples in flight inside one launch (one tuple per wavefront, so
     // fewer wavefronts); the group kernels are launched in windows of that many tuples.
     if (!history && e->stale_window > 0 && e->stale_window < window) window = e->stale_window;
     for (int64_t o = 0; o < n; o += window) {
         const int64_t len = std::min(window, n - o);
-        int rc = history ? launch_sgd_history(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic, e->stale_window, e->st)
+        int rc = history ? launch_sgd_history(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic, e->stale_window, user_batch, e->st)
                  : ((grouped || e->group == 1) && sgd_runs_supported(model)) ? launch_sgd_runs(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic, e->run_segment, e->run_policy, e->st)
                          : launch_sgd_hogwild(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic, e->st);
         if (rc) return rc;
@@ -572,10 +580,18 @@ extern "C" int rec_sgd_replay(rec_engine* e, double lr, const int32_t* tuples, i
         if (int rc = launch_sgd_sequential(e->dm, e->desc.precision, e->tuples, n, lr, e->st)) return rc;
         ENG_HIP(hipStreamSynchronize(e->st));
     } else if (mode == REC_REPLAY_HOGWILD) {
-        for (int64_t o = 0; o < n; o += e->chunk) {
-            const int64_t len = std::min(e->chunk, n - o);
+        const int ub = history_model(e->desc.model) ? e->user_batch : 1;
+        int64_t chunk = e->chunk;
+        if (ub > 1) {
+            // the batched kernel takes every aligned group of user_batch tuples as one user's
+            for (int64_t i = 0; i < n; i++)
+                if (tuples[4 * i] != tuples[4 * (i - i % ub)]) { rec_set_error("tuple " + std::to_string(i) + ": user_batch is set but the tuples are not grouped by user"); return -1; }
+            chunk = std::max<int64_t>(8, chunk & ~(int64_t)7);
+        }
+        for (int64_t o = 0; o < n; o += chunk) {
+            const int64_t len = std::min(chunk, n - o);
             if (int rc = ev_begin(e, 0, &a, &b)) return rc;
-            if (int rc = launch_update(e, e->tuples + o, len, lr)) return rc;
+            if (int rc = launch_update(e, e->tuples + o, len, lr, false, ub)) return rc;
             if (int rc = ev_end(e, 0, a, b)) return rc;
         }
         // the host buffer may be reused by the caller: the copy above must have completed
@@ -592,7 +608,9 @@ extern "C" int rec_sgd_epoch(rec_engine* e, double lr, int64_t n_steps, uint64_t
     if (e->desc.model == REC_MP) { rec_set_error("MostPopular has nothing to train"); return -1; }
     if (n_steps <= 0) return 0;
     ENG_HIP(hipSetDevice(e->desc.device));
-    const int64_t chunk = std::min(e->chunk, n_steps);
+    const int ub = history_model(e->desc.model) ? e->user_batch : 1;
+    int64_t chunk = std::min(e->chunk, n_steps);
+    if (ub > 1) chunk = (chunk + 7) & ~(int64_t)7;   // chunks start on a group boundary
     // event-major chunks have a Poisson-distributed length: room for 8 standard deviations
     const bool grouped = e->group >= 2 && sgd_runs_supported(e->desc.model) && (e->stale_window == 0 || e->stale_window >= chunk);
     if (grouped) { if (int rc = ensure_events(e)) return rc; }
@@ -613,7 +631,7 @@ extern "C" int rec_sgd_epoch(rec_engine* e, double lr, int64_t n_steps, uint64_t
         if (grouped) {
             if (int rc = launch_event_sampler(e->dm, tb, e->tuples_cap, len, o, (uint64_t)c, seed, epoch, e->group_scratch, e->n_drawn_dev, ss)) return rc;
         } else {
-            if (int rc = launch_sampler(e->dm, tb, len, o, seed, epoch, ss)) return rc;
+            if (int rc = launch_sampler(e->dm, tb, len, o, seed, epoch, ss, ub)) return rc;
         }
         if (e->profile) { ENG_HIP(hipEventRecord(b, ss)); e->pending[2].push_back({a, b}); }
         if (grouped) {
@@ -628,7 +646,7 @@ extern "C" int rec_sgd_epoch(rec_engine* e, double lr, int64_t n_steps, uint64_t
             ENG_HIP(hipStreamWaitEvent(e->st, e->ev_sampled[buf], 0));
         }
         if (int rc = ev_begin(e, 0, &a, &b)) return rc;
-        if (int rc = launch_update(e, tb, len, lr, grouped && e->group == 2)) return rc;
+        if (int rc = launch_update(e, tb, len, lr, grouped && e->group == 2, ub)) return rc;
         if (int rc = ev_end(e, 0, a, b)) return rc;
         if (e->overlap) { ENG_HIP(hipEventRecord(e->ev_consumed[buf], e->st)); e->consumed_valid[buf] = true; }
         e->tuples_drawn += len;
@@ -658,7 +676,7 @@ extern "C" int rec_sample_tuples(rec_engine* e, int64_t n, uint64_t seed, uint64
     if (n <= 0) return 0;
     ENG_HIP(hipSetDevice(e->desc.device));
     if (int rc = ensure_tuples(e, n)) return rc;
-    if (int rc = launch_sampler(e->dm, e->tuples, n, 0, seed, epoch, e->st)) return rc;
+    if (int rc = launch_sampler(e->dm, e->tuples, n, 0, seed, epoch, e->st, history_model(e->desc.model) ? e->user_batch : 1)) return rc;
     ENG_HIP(hipMemcpyAsync(out, e->tuples, sizeof(int4) * n, hipMemcpyDeviceToHost, e->st));
     ENG_HIP(hipStreamSynchronize(e->st));
     return 0;
@@ -806,6 +824,7 @@ extern "C" int rec_set_option(rec_engine* e, const char* name, int64_t value)
     else if (s == "run_shared") { if (value < 1) { rec_set_error("run_shared must be positive"); return -1; } e->run_policy.shared = (int)value; }
     else if (s == "run_hot") { if (value < 1) { rec_set_error("run_hot must be positive"); return -1; } e->run_policy.hot = (int)value; }
     else if (s == "run_hot_atomic") e->run_policy.hot_atomic = value != 0;
+    else if (s == "user_batch") { if (value != 1 && value != 2 && value != 4 && value != 8) { rec_set_error("user_batch must be 1, 2, 4 or 8"); return -1; } e->user_batch = (int)value; }
     else if (s == "run_segment") { if (value < 0) { rec_set_error("run_segment must be >= 0"); return -1; } e->run_segment = value; }
     else if (s == "group_by_item") { if (value < 0 || value > 3) { rec_set_error("group_by_item must be 0..3"); return -1; } e->group = (int)value; }
     else if (s == "hot_count") {

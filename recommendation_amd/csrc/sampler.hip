@@ -26,12 +26,15 @@ struct Rng {
 
 template <int MODEL>
 __global__ void __launch_bounds__(256) sampler_kernel(DevModel m, int4* __restrict__ out, int64_t n, int64_t first_step,
-                                                      uint64_t seed, uint64_t epoch)
+                                                      uint64_t seed, uint64_t epoch, int user_batch)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Rng rng(seed, epoch, (uint64_t)(first_step + i));
-    const int pick = (int)bounded(rng.next(), (uint32_t)m.n_elig);
+    uint32_t r_owner = rng.next();
+    // user_batch > 1: steps g*user_batch .. (g+1)*user_batch-1 share one owner draw, everything else stays per step
+    if (user_batch > 1) { Rng ro(seed ^ 0xD1B54A32D192ED03ull, epoch, (uint64_t)(first_step + i) / (uint64_t)user_batch); r_owner = ro.next(); }
+    const int pick = (int)bounded(r_owner, (uint32_t)m.n_elig);
     const int e = m.elig_identity ? pick : m.elig[pick];   // every owner eligible: the list is 0..n-1
     int4 t = make_int4(e, 0, 0, 0);
     if constexpr (MODEL == REC_MC) {
@@ -106,12 +109,12 @@ __global__ void __launch_bounds__(256) sampler_kernel(DevModel m, int4* __restri
 }
 
 int launch_sampler(const DevModel& m, int4* tuples, int64_t n, int64_t first_step, uint64_t seed, uint64_t epoch,
-                   hipStream_t st)
+                   hipStream_t st, int user_batch)
 {
     if (n <= 0) return 0;
     if (m.n_elig <= 0) { rec_set_error("no user (or source item) is eligible for sampling"); return -1; }
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-#define SAMPLER_CASE(M) case M: hipLaunchKernelGGL(sampler_kernel<M>, grid, block, 0, st, m, tuples, n, first_step, seed, epoch); break;
+#define SAMPLER_CASE(M) case M: hipLaunchKernelGGL(sampler_kernel<M>, grid, block, 0, st, m, tuples, n, first_step, seed, epoch, user_batch); break;
     switch (m.model) {
         SAMPLER_CASE(REC_BPRMF) SAMPLER_CASE(REC_MC) SAMPLER_CASE(REC_FPMC) SAMPLER_CASE(REC_PRME)
         SAMPLER_CASE(REC_HRM_AVG) SAMPLER_CASE(REC_HRM_MAX) SAMPLER_CASE(REC_TRANSREC) SAMPLER_CASE(REC_TRANSREC_L1)

@@ -1,51 +1,109 @@
 // Hogwild BPR-SGD step of the models whose tuple touches a variable number of rows: Fossil,
-// FossilSimple and REBUS.  One wavefront per tuple; lane l owns components k = l, l+64, ...
+// FossilSimple and REBUS (Fossil.cpp:140-252, FossilSimple.cpp:151-235, REBUS.cpp:282-444).
+// One wavefront per group of G consecutive tuples of one user (G = 1 unless the sampler option
+// user_batch groups them); lane l owns components k = l, l+64, ...
 //
 // A tuple reads every item row of the user's history (Fossil: the whole training sequence with
 // repeats, Fossil.cpp:140-153; REBUS: the distinct items of the prefix, REBUS.cpp:305-318) twice:
-// pass 1 streams the rows into the two history sums (eight rows in flight per wave at K <= 64), pass 2 re-reads
-// each row (an L2 / Infinity Cache hit) for its own regulariser term and scatters its delta with
-// float atomics.  The rows of the CSR are consecutive in seq_item, so the item ids themselves are
-// read as coalesced runs.
+// pass 1 streams the rows into the history sums, pass 2 re-reads each row (an L2 / Infinity Cache
+// hit) for its own regulariser term and scatters its delta with float atomics.  The rows of the CSR
+// are consecutive in seq_item, so the item ids themselves are read as coalesced runs.
+// The G tuples of a group read the same rows, so the rows are streamed once per group: pass 1
+// accumulates the G pairs of sums side by side, pass 2 scatters the sum of the G deltas (every
+// tuple's regulariser term included) with one atomic per component.  All G tuples see the parameters
+// as they were when the group started, which is what tuples in flight on different wavefronts see of
+// each other anyway.
 // Parameters that every tuple touches are not scattered per tuple (their atomics would all hit one
 // address): Fossil's global weights WT[0..L) and FossilSimple's alpha collect their gradient sums
 // per block and are folded in by launch_apply_global_history after the launch; they stay constant
 // during a launch.
 #include "common.h"
 
-#define E REC_MAX_EPL
-
+namespace {
 template <class T>
 __device__ __forceinline__ void scat(T* p, T delta, T oldv, bool atomic)
 {
     if (atomic) unsafeAtomicAdd(p, delta);
     else *p = oldv + delta;
 }
-
+// A value that is the same on every lane of the wavefront, moved to a scalar register: comparisons on it become
+// scalar branches and row addresses built from it a scalar base plus the lane's offset.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t uni(int64_t v)
+{
+    return (int64_t)(((uint64_t)(uint32_t)uni((int)((uint64_t)v >> 32)) << 32) | (uint32_t)uni((int)(uint32_t)v));
+}
 template <class T> __device__ __forceinline__ T sigm(T x) { return (T)1 / ((T)1 + rexp(x)); }
 template <class T> __device__ __forceinline__ T wsum(T v) { return group_sum<64>(v); }
 
-// gacc layout: [0, L) gradient sums, [L, 2L) number of tuples that contributed (Fossil); [0], [1] for FossilSimple
-template <int MODEL, class T, int EPL>
-__global__ void __launch_bounds__(256) sgd_history_kernel(DevModel m, const int4* __restrict__ tuples, int64_t n, T lr, int atomic)
+// Walks the rows tab[seq[h]] for h in [0, hend) (only positions with first[h] set when `first` is given), RIF rows
+// per round, and calls body(h, item, row components of this lane).  The rows of round r+1 are requested before
+// the body of round r runs: memory operations retire in order on a wavefront, so a body that ends in atomics
+// would otherwise make the next round's loads wait for those atomics to come back.  A row that round r updates
+// and round r+1 reads again (a repeated item) is therefore read before its update.
+template <int RIF, int EPL, class T, class Body>
+__device__ __forceinline__ void walk_history(const T* tab, const int32_t* seq, const uint8_t* first, const uint8_t* hot, int K, int lane,
+                                             int hend, Body body)
 {
-    constexpr int RIF = EPL == 1 ? 8 : 4;   // history rows in flight per wavefront
+    int itA[RIF], itB[RIF], hotA[RIF], hotB[RIF]; T xA[RIF][EPL], xB[RIF][EPL];
+    auto load = [&](int h0, int (&it)[RIF], int (&hf)[RIF], T (&x)[RIF][EPL]) {
+#pragma unroll
+        for (int q = 0; q < RIF; q++) {
+            const int h = h0 + q;
+            it[q] = (h < hend && (!first || uni((int)first[h]))) ? uni(seq[h]) : -1;
+#pragma unroll
+            for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; x[q][j] = (it[q] >= 0 && k < K) ? tab[(int64_t)it[q] * K + k] : (T)0; }
+            // the item's hot flag travels with its row: fetched when the scatter needs it, it would cost a round trip per row
+            hf[q] = (hot && it[q] >= 0) ? (int)hot[it[q]] : 0;
+        }
+    };
+    load(0, itA, hotA, xA);
+    for (int h0 = 0; h0 < hend; h0 += RIF) {
+        load(h0 + RIF, itB, hotB, xB);
+#pragma unroll
+        for (int q = 0; q < RIF; q++) { if (itA[q] >= 0) body(h0 + q, itA[q], xA[q], hotA[q] != 0); }
+#pragma unroll
+        for (int q = 0; q < RIF; q++) {
+            itA[q] = itB[q]; hotA[q] = hotB[q];
+#pragma unroll
+            for (int j = 0; j < EPL; j++) xA[q][j] = xB[q][j];
+        }
+    }
+}
+
+template <int MODEL, class T, int EPL, int G>
+__global__ void __launch_bounds__(256) sgd_history_batch_kernel(DevModel m, const int4* __restrict__ tuples, int64_t n, T lr, int atomic)
+{
+    constexpr int RIF = EPL == 1 ? 8 : 4;   // history rows per round
     const int lane = threadIdx.x & 63;
-    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int K = m.K, L = m.L, I = m.I;
     const T lam = (T)m.lambda, breg = (T)m.bias_reg;
     const bool at_item = (atomic >> 1) & 1, at_user = atomic & 1, at_bias = (atomic >> 8) & 1;
+    const int64_t ngroups = (n + G - 1) / G;
 
-    // per-lane accumulators of the global gradients: lane `ind` holds WT[ind]'s (Fossil), lane 0 alpha's (FossilSimple)
-    T gsum = 0, gcnt = 0;
+    T gsum = 0, gcnt = 0;   // Fossil: lane ind collects WT[ind]'s gradient; FossilSimple: lane 0 alpha's
 
-    for (int64_t i = wid; i < n; i += nwaves) {
-        const int4 t = tuples[i];
-        const int u = t.x;
-        const int64_t so = m.seq_off[u];
+    // Groups are claimed from a counter, CLAIM at a time: a group's work is proportional to the length of its
+    // user's history, which varies too much for a fixed assignment of groups to wavefronts to balance.  (One
+    // claim per tuple would make the counter the bottleneck: atomics on one address retire about 16 ns apart.)
+    // The claim that follows is issued before the claimed groups' work and read after it.
+    constexpr int CLAIM = G >= 8 ? 1 : 8 / G;
+    int next = 0;
+    if (lane == 0) next = atomicAdd(m.work_counter, 1);
+    for (;;) {
+        const int64_t first = (int64_t)uni(next) * CLAIM;
+        if (first >= ngroups) break;
+        if (lane == 0) next = atomicAdd(m.work_counter, 1);
+      for (int64_t gi = first; gi < first + CLAIM && gi < ngroups; gi++) {
+        const int64_t base = gi * G;
+        const int ng = (int)(n - base < G ? n - base : G);
+        int4 tg[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) tg[g] = tuples[base + (g < ng ? g : 0)];
+        const int u = uni(tg[0].x);
+        const int64_t so = uni(m.seq_off[u]);
         const int32_t* seq = m.seq_item + so;
-        const int nu = (int)(m.seq_off[u + 1] - so);
+        const int nu = uni((int)(m.seq_off[u + 1] - so));
 
         if constexpr (MODEL == REC_FOSSIL || MODEL == REC_FOSSIL_SIMPLE) {
             constexpr bool SIMPLE = MODEL == REC_FOSSIL_SIMPLE;
@@ -53,233 +111,267 @@ __global__ void __launch_bounds__(256) sgd_history_kernel(DevModel m, const int4
             T* Ui = (T*)m.tab[SIMPLE ? FS_UI : FO_UI];
             T* V = (T*)m.tab[SIMPLE ? FS_V : FO_V];
             // tuple: Fossil (u, t, neg, -), FossilSimple (u, prev, pos, neg)
-            const int tpos = SIMPLE ? 0 : t.y;
-            const int pos = SIMPLE ? t.z : seq[tpos];
-            const int neg = SIMPLE ? t.w : t.z;
-            const int np = SIMPLE ? 1 : (tpos < L ? tpos : L);
-            T* Vp = V + (int64_t)pos * K; T* Vn = V + (int64_t)neg * K;
-            T vp[EPL], vn[EPL], sp[EPL], sn[EPL];
+            int pos[G], neg[G], np[G], prevl[G];   // prevl: lane ind holds the ind-th previous item of tuple g
+            int hp[G], hn[G];                      // hot flags of pos / neg, fetched with their rows
+            T vp[G][EPL], vn[G][EPL], sp[G][EPL], sn[G][EPL];
 #pragma unroll
-            for (int j = 0; j < EPL; j++) {
-                const int k = lane + 64 * j; sp[j] = sn[j] = 0;
-                vp[j] = k < K ? Vp[k] : (T)0; vn[j] = k < K ? Vn[k] : (T)0;
+            for (int g = 0; g < G; g++) {
+                const bool valid = g < ng;
+                const int tpos = SIMPLE ? 0 : uni(tg[g].y);
+                pos[g] = valid ? uni(SIMPLE ? tg[g].z : seq[tpos]) : -1;
+                neg[g] = valid ? uni(SIMPLE ? tg[g].w : tg[g].z) : -1;
+                np[g] = valid ? (SIMPLE ? 1 : (tpos < L ? tpos : L)) : 0;
+                prevl[g] = lane < np[g] ? (SIMPLE ? tg[g].y : seq[tpos - 1 - lane]) : -2;
+                hp[g] = (valid && (at_item || at_bias)) ? m.hot[pos[g]] : 0; hn[g] = (valid && (at_item || at_bias)) ? m.hot[neg[g]] : 0;
+#pragma unroll
+                for (int j = 0; j < EPL; j++) {
+                    const int k = lane + 64 * j; sp[g][j] = sn[g][j] = 0;
+                    vp[g][j] = (valid && k < K) ? V[(int64_t)pos[g] * K + k] : (T)0;
+                    vn[g][j] = (valid && k < K) ? V[(int64_t)neg[g] * K + k] : (T)0;
+                }
             }
             // pass 1: history sums, Fossil.cpp:140-153
-            int cp = 0, cn = 0;
-            for (int h0 = 0; h0 < nu; h0 += RIF) {
-                int it[RIF]; T x[RIF][EPL];
+            int cp[G], cn[G];
 #pragma unroll
-                for (int q = 0; q < RIF; q++) {
-                    it[q] = h0 + q < nu ? seq[h0 + q] : -1;
+            for (int g = 0; g < G; g++) cp[g] = cn[g] = 0;
+            walk_history<RIF, EPL, T>(Ui, seq, nullptr, nullptr, K, lane, nu, [&](int, int c, const T (&x)[EPL], bool) {
 #pragma unroll
-                    for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; x[q][j] = (it[q] >= 0 && k < K) ? Ui[(int64_t)it[q] * K + k] : (T)0; }
+                for (int g = 0; g < G; g++) {
+                    const bool a = c != pos[g], b = c != neg[g];
+                    cp[g] += a; cn[g] += b;
+#pragma unroll
+                    for (int j = 0; j < EPL; j++) { sp[g][j] += a ? x[j] : (T)0; sn[g][j] += b ? x[j] : (T)0; }
                 }
-#pragma unroll
-                for (int q = 0; q < RIF; q++) {
-                    if (it[q] < 0) continue;
-                    if (it[q] != pos) cp++;
-                    if (it[q] != neg) cn++;
-#pragma unroll
-                    for (int j = 0; j < EPL; j++) { if (it[q] != pos) sp[j] += x[q][j]; if (it[q] != neg) sn[j] += x[q][j]; }
-                }
-            }
-            const T wp = cp > 0 ? rpow((T)cp, (T)-0.2) : (T)0, wn = cn > 0 ? rpow((T)cn, (T)-0.2) : (T)0;
+            });
             // short-term weights: lane ind holds WT[ind] + WTu[u][ind] (Fossil) / lane 0 alpha + alpha_u[u] (FossilSimple)
             T wt_g = 0, wt_u = 0;
-            if (lane < np) {
+            if (lane < (SIMPLE ? 1 : L)) {
                 if (SIMPLE) { wt_g = ((T*)m.tab[FS_ALPHA])[0]; wt_u = ((T*)m.tab[FS_ALPHA_U])[u]; }
                 else { wt_g = ((T*)m.tab[FO_WT])[lane]; wt_u = ((T*)m.tab[FO_WTU])[(int64_t)u * L + lane]; }
             }
             const T wt = wt_g + wt_u;
+            T wp[G], wn[G], deri[G];
+            T user_delta = 0;   // this lane's WTu[u][lane] / alpha_u[u] delta summed over the group
+            T bp[G], bn[G];     // lane 0: the biases as the group found them
 #pragma unroll
-            for (int j = 0; j < EPL; j++) { sp[j] *= wp; sn[j] *= wn; }
-            T grad_mine = 0;   // d loss / d weight of this lane's ind, filled below
-            for (int ind = 0; ind < np; ind++) {
-                const int c = SIMPLE ? t.y : seq[tpos - 1 - ind];
-                const T w = __shfl(wt, ind, 64);
-                T d1 = 0, d2 = 0;
+            for (int g = 0; g < G; g++) { bp[g] = (lane == 0 && g < ng) ? beta[pos[g]] : (T)0; bn[g] = (lane == 0 && g < ng) ? beta[neg[g]] : (T)0; }
 #pragma unroll
-                for (int j = 0; j < EPL; j++) {
-                    const int k = lane + 64 * j;
-                    const T x = k < K ? Ui[(int64_t)c * K + k] : (T)0;
-                    // FossilSimple adds the short-term term on both sides unconditionally (FossilSimple.cpp:180-181)
-                    if (SIMPLE || c != pos) sp[j] += w * x;
-                    if (SIMPLE || c != neg) sn[j] += w * x;
-                    d1 += x * vp[j]; d2 += x * vn[j];
-                }
-                d1 = wsum(d1); d2 = wsum(d2);
-                // Fossil.cpp:194-206 (three cases); FossilSimple.cpp:195-196 (always the difference)
-                const T gI = (SIMPLE || (c != pos && c != neg)) ? d1 - d2 : (c != pos ? d1 : -d2);
-                if (lane == ind) grad_mine = gI;
-            }
-            T s1 = 0, s2 = 0;
+            for (int g = 0; g < G; g++) {
+                wp[g] = cp[g] > 0 ? rpow((T)cp[g], (T)-0.2) : (T)0; wn[g] = cn[g] > 0 ? rpow((T)cn[g], (T)-0.2) : (T)0;
+                if (g >= ng) { wp[g] = wn[g] = 0; deri[g] = 0; continue; }
 #pragma unroll
-            for (int j = 0; j < EPL; j++) { s1 += sp[j] * vp[j]; s2 += sn[j] * vn[j]; }
-            T bpos = 0, bneg = 0;
-            if (lane == 0) { bpos = beta[pos]; bneg = beta[neg]; }
-            const T x_uij = __shfl(bpos - bneg, 0, 64) + (wsum(s1) - wsum(s2));
-            const T deri = sigm(x_uij);
-            if (lane == 0) {
-                scat(beta + pos, lr * (deri - breg * bpos), bpos, at_bias && !m.hot[pos]);
-                scat(beta + neg, lr * (-deri - breg * bneg), bneg, at_bias && !m.hot[neg]);
-            }
-            if (lane < np) {
-                // per-user weight now; the global weight only collects its gradient
-                gsum += deri * grad_mine; gcnt += 1;
-                if (SIMPLE) {
-                    T* au = (T*)m.tab[FS_ALPHA_U] + u;
-                    scat(au, lr * (deri * grad_mine - lam * wt_u), wt_u, at_user);
-                } else {
-                    const int c = seq[tpos - 1 - lane];
-                    // "- lambda * WT[ind]" in the two aliasing branches, Fossil.cpp:201,205
-                    const T regv = (c != pos && c != neg) ? wt_u : wt_g;
-                    T* wu = (T*)m.tab[FO_WTU] + (int64_t)u * L + lane;
-                    scat(wu, lr * (deri * grad_mine - lam * regv), wt_u, at_user);
-                }
-            }
-            // pass 2: every history row, Fossil.cpp:209-247 / FossilSimple.cpp:198-226
-            for (int h0 = 0; h0 < nu; h0 += RIF) {
-                int it[RIF]; T x[RIF][EPL];
-#pragma unroll
-                for (int q = 0; q < RIF; q++) {
-                    it[q] = h0 + q < nu ? seq[h0 + q] : -1;
-#pragma unroll
-                    for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; x[q][j] = (it[q] >= 0 && k < K) ? Ui[(int64_t)it[q] * K + k] : (T)0; }
-                }
-#pragma unroll
-                for (int q = 0; q < RIF; q++) {
-                    if (it[q] < 0) continue;
-                    const int c = it[q];
-                    T a = 0; bool inprev = false;
-                    if (SIMPLE) { inprev = c == t.y; a = __shfl(wt, 0, 64); }
-                    else {
-                        int pt = -1;
-                        for (int ind = 0; ind < np; ind++) if (seq[tpos - 1 - ind] == c) { pt = ind; break; }
-                        inprev = pt >= 0;
-                        a = __shfl(wt, pt >= 0 ? pt : 0, 64);
-                    }
-                    if (!inprev) a = 0;
-                    T cpz, cnz;   // delta = lr * (deri * (cpz * Vp - cnz * Vn) - lambda * U_c)
-                    if (SIMPLE && inprev) { cpz = wp + a; cnz = wn + a; }                       // FossilSimple.cpp:199-203
-                    else if (c != pos) { cpz = wp + a; cnz = c != neg ? wn + a : (T)0; }
-                    else { cpz = 0; cnz = wn + a; }
-                    const bool atc = at_item && !m.hot[c];
-                    T* row = Ui + (int64_t)c * K;
+                for (int j = 0; j < EPL; j++) { sp[g][j] *= wp[g]; sn[g][j] *= wn[g]; }
+                T grad_mine = 0;
+                for (int ind = 0; ind < np[g]; ind++) {
+                    const int c = uni(__shfl(prevl[g], ind, 64));
+                    const T w = __shfl(wt, ind, 64);
+                    T d1 = 0, d2 = 0;
 #pragma unroll
                     for (int j = 0; j < EPL; j++) {
                         const int k = lane + 64 * j;
-                        if (k < K) scat(row + k, lr * (deri * (cpz * vp[j] - cnz * vn[j]) - lam * x[q][j]), x[q][j], atc);
+                        const T x = k < K ? Ui[(int64_t)c * K + k] : (T)0;
+                        // FossilSimple adds the short-term term on both sides unconditionally (FossilSimple.cpp:180-181)
+                        if (SIMPLE || c != pos[g]) sp[g][j] += w * x;
+                        if (SIMPLE || c != neg[g]) sn[g][j] += w * x;
+                        d1 += x * vp[g][j]; d2 += x * vn[g][j];
                     }
+                    d1 = wsum(d1); d2 = wsum(d2);
+                    // Fossil.cpp:194-206 (three cases); FossilSimple.cpp:195-196 (always the difference)
+                    const T gI = (SIMPLE || (c != pos[g] && c != neg[g])) ? d1 - d2 : (c != pos[g] ? d1 : -d2);
+                    if (lane == ind) grad_mine = gI;
+                }
+                T s1 = 0, s2 = 0;
+#pragma unroll
+                for (int j = 0; j < EPL; j++) { s1 += sp[g][j] * vp[g][j]; s2 += sn[g][j] * vn[g][j]; }
+                const T bpos = bp[g], bneg = bn[g];
+                const T x_uij = __shfl(bpos - bneg, 0, 64) + (wsum(s1) - wsum(s2));
+                deri[g] = sigm(x_uij);
+                if (lane == 0) {
+                    scat(beta + pos[g], lr * (deri[g] - breg * bpos), bpos, at_bias && !hp[g]);
+                    scat(beta + neg[g], lr * (-deri[g] - breg * bneg), bneg, at_bias && !hn[g]);
+                }
+                if (lane < np[g]) {
+                    gsum += deri[g] * grad_mine; gcnt += 1;
+                    // "- lambda * WT[ind]" in the two aliasing branches, Fossil.cpp:201,205
+                    const T regv = (SIMPLE || (prevl[g] != pos[g] && prevl[g] != neg[g])) ? wt_u : wt_g;
+                    user_delta += lr * (deri[g] * grad_mine - lam * regv);
                 }
             }
+            if (lane < (SIMPLE ? 1 : L) && user_delta != (T)0) {
+                T* wu = SIMPLE ? (T*)m.tab[FS_ALPHA_U] + u : (T*)m.tab[FO_WTU] + (int64_t)u * L + lane;
+                scat(wu, user_delta, wt_u, at_user);
+            }
+            // pass 2: every history row once for the whole group, Fossil.cpp:209-247 / FossilSimple.cpp:198-226
+            const T wt0 = __shfl(wt, 0, 64);
+            const T reg = lam * (T)ng;
+            walk_history<RIF, EPL, T>(Ui, seq, nullptr, at_item ? m.hot : nullptr, K, lane, nu, [&](int, int c, const T (&x)[EPL], bool c_hot) {
+                T d[EPL];
+#pragma unroll
+                for (int j = 0; j < EPL; j++) d[j] = 0;
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    const uint64_t hit = __ballot(prevl[g] == c);
+                    const bool inprev = hit != 0;
+                    T a = 0;
+                    if (inprev) a = SIMPLE ? wt0 : __shfl(wt, (int)__ffsll((unsigned long long)hit) - 1, 64);
+                    T cpz, cnz;   // delta_g = deri * (cpz * Vp - cnz * Vn)
+                    if (SIMPLE && inprev) { cpz = wp[g] + a; cnz = wn[g] + a; }                       // FossilSimple.cpp:199-203
+                    else if (c != pos[g]) { cpz = wp[g] + a; cnz = c != neg[g] ? wn[g] + a : (T)0; }
+                    else { cpz = 0; cnz = wn[g] + a; }
+                    cpz *= deri[g]; cnz *= deri[g];
+#pragma unroll
+                    for (int j = 0; j < EPL; j++) d[j] += cpz * vp[g][j] - cnz * vn[g][j];
+                }
+                const bool atc = at_item && !c_hot;
+                T* row = Ui + (int64_t)c * K;
+#pragma unroll
+                for (int j = 0; j < EPL; j++) {
+                    const int k = lane + 64 * j;
+                    if (k < K) scat(row + k, lr * (d[j] - reg * x[j]), x[j], atc);
+                }
+            });
             // Fossil.cpp:249-252
 #pragma unroll
-            for (int j = 0; j < EPL; j++) {
-                const int k = lane + 64 * j;
-                if (k < K) {
-                    scat(Vp + k, lr * (deri * sp[j] - lam * vp[j]), vp[j], at_item && !m.hot[pos]);
-                    scat(Vn + k, lr * (-deri * sn[j] - lam * vn[j]), vn[j], at_item && !m.hot[neg]);
+            for (int g = 0; g < G; g++) {
+                if (g >= ng) continue;
+                T* Vp = V + (int64_t)pos[g] * K; T* Vn = V + (int64_t)neg[g] * K;
+                const bool ap = at_item && !hp[g], an = at_item && !hn[g];
+#pragma unroll
+                for (int j = 0; j < EPL; j++) {
+                    const int k = lane + 64 * j;
+                    if (k < K) {
+                        scat(Vp + k, lr * (deri[g] * sp[g][j] - lam * vp[g][j]), vp[g][j], ap);
+                        scat(Vn + k, lr * (-deri[g] * sn[g][j] - lam * vn[g][j]), vn[g][j], an);
+                    }
                 }
             }
         } else {
-            // ---------------- REBUS, REBUS.cpp:282-444; tuple (u, t-1, neg, -)
+            // ---------------- REBUS, REBUS.cpp:282-444; tuple (u, t-1, neg, -): the history of tuple g is seq[0, tpos[g])
             T* beta = (T*)m.tab[RB_BETA]; T* P = (T*)m.tab[RB_P];
-            const int tpos = t.y + 1, neg = t.z;
-            const int pos = seq[tpos];
             const uint8_t* fo = m.first_occ + so;
-            const int64_t ctx = so + 2 * (int64_t)u + (tpos - 1);
-            const int32_t* path = m.path_item + m.path_off[ctx];
-            const int np = (int)(m.path_off[ctx + 1] - m.path_off[ctx]);
-            const double* etas = m.eta + (int64_t)np * L;
-            T pp[EPL], pn[EPL], sp[EPL], sn[EPL], sl[EPL];
+            int hp[G], hn[G];                               // hot flags of pos / neg, fetched with their rows
+            int tpos[G], pos[G], neg[G], np[G], pathl[G];   // pathl / etal: lane r holds the r-th item of tuple g's matched path and its weight
+            T etal[G];
+            T pp[G][EPL], pn[G][EPL], sp[G][EPL], sn[G][EPL];
+            int tmax = 0;
 #pragma unroll
-            for (int j = 0; j < EPL; j++) {
-                const int k = lane + 64 * j; sp[j] = sn[j] = sl[j] = 0;
-                pp[j] = k < K ? P[(int64_t)pos * K + k] : (T)0; pn[j] = k < K ? P[(int64_t)neg * K + k] : (T)0;
-            }
-            int cp = 0, cn = 0; bool pos_in = false, neg_in = false;
-            for (int h0 = 0; h0 < tpos; h0 += RIF) {
-                int it[RIF]; T x[RIF][EPL];
-#pragma unroll
-                for (int q = 0; q < RIF; q++) {
-                    it[q] = (h0 + q < tpos && fo[h0 + q]) ? seq[h0 + q] : -1;
-#pragma unroll
-                    for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; x[q][j] = (it[q] >= 0 && k < K) ? P[(int64_t)it[q] * K + k] : (T)0; }
+            for (int g = 0; g < G; g++) {
+                const bool valid = g < ng;
+                tpos[g] = valid ? uni(tg[g].y) + 1 : 0;
+                pos[g] = valid ? uni(seq[tpos[g]]) : -1;
+                neg[g] = valid ? uni(tg[g].z) : -1;
+                np[g] = 0; pathl[g] = -2; etal[g] = 0;
+                if (valid) {
+                    const int64_t ctx = so + 2 * (int64_t)u + (tpos[g] - 1);
+                    const int64_t po = uni(m.path_off[ctx]);
+                    np[g] = uni((int)(m.path_off[ctx + 1] - po));
+                    if (lane < np[g]) { pathl[g] = m.path_item[po + lane]; etal[g] = (T)m.eta[(int64_t)np[g] * L + lane]; }
                 }
+                hp[g] = (valid && (at_item || at_bias)) ? m.hot[pos[g]] : 0; hn[g] = (valid && (at_item || at_bias)) ? m.hot[neg[g]] : 0;
+                tmax = tpos[g] > tmax ? tpos[g] : tmax;
 #pragma unroll
-                for (int q = 0; q < RIF; q++) {
-                    if (it[q] < 0) continue;
-                    if (it[q] != pos) cp++; else pos_in = true;
-                    if (it[q] != neg) cn++; else neg_in = true;
-#pragma unroll
-                    for (int j = 0; j < EPL; j++) { if (it[q] != pos) sp[j] += x[q][j]; if (it[q] != neg) sn[j] += x[q][j]; }
+                for (int j = 0; j < EPL; j++) {
+                    const int k = lane + 64 * j; sp[g][j] = sn[g][j] = 0;
+                    pp[g][j] = (valid && k < K) ? P[(int64_t)pos[g] * K + k] : (T)0;
+                    pn[g][j] = (valid && k < K) ? P[(int64_t)neg[g] * K + k] : (T)0;
                 }
             }
-            const T wp = cp > 0 ? rpow((T)cp, (T)m.alpha) : (T)0, wn = cn > 0 ? rpow((T)cn, (T)m.alpha) : (T)0;
-            T proot[EPL];   // the Root row, when the path is empty (REBUS.cpp:414-418)
-            for (int r = 0; r < np; r++) {
-                const int c = path[r]; const T e = (T)etas[r];
+            int cp[G], cn[G]; unsigned pos_in = 0, neg_in = 0;
+#pragma unroll
+            for (int g = 0; g < G; g++) cp[g] = cn[g] = 0;
+            walk_history<RIF, EPL, T>(P, seq, fo, nullptr, K, lane, tmax, [&](int h, int c, const T (&x)[EPL], bool) {
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    const bool in = h < tpos[g];
+                    const bool a = in && c != pos[g], b = in && c != neg[g];
+                    cp[g] += a; cn[g] += b;
+                    if (in && !a) pos_in |= 1u << g;
+                    if (in && !b) neg_in |= 1u << g;
+#pragma unroll
+                    for (int j = 0; j < EPL; j++) { sp[g][j] += a ? x[j] : (T)0; sn[g][j] += b ? x[j] : (T)0; }
+                }
+            });
+            T wp[G], wn[G], deri[G];
+            T bp[G], bn[G];     // lane 0: the biases as the group found them
+#pragma unroll
+            for (int g = 0; g < G; g++) { bp[g] = (lane == 0 && g < ng) ? beta[pos[g]] : (T)0; bn[g] = (lane == 0 && g < ng) ? beta[neg[g]] : (T)0; }
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                wp[g] = cp[g] > 0 ? rpow((T)cp[g], (T)m.alpha) : (T)0; wn[g] = cn[g] > 0 ? rpow((T)cn[g], (T)m.alpha) : (T)0;
+                if (g >= ng) { deri[g] = 0; continue; }
+                T sl[EPL];
+#pragma unroll
+                for (int j = 0; j < EPL; j++) sl[j] = 0;
+                for (int r = 0; r < np[g]; r++) {
+                    const int c = uni(__shfl(pathl[g], r, 64)); const T e = __shfl(etal[g], r, 64);
+#pragma unroll
+                    for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; sl[j] += e * (k < K ? P[(int64_t)c * K + k] : (T)0); }
+                }
+                // sp / sn become the two distance vectors from here on
+                T qp = 0, qn = 0;
+#pragma unroll
+                for (int j = 0; j < EPL; j++) {
+                    sp[g][j] = wp[g] * sp[g][j] + sl[j] - pp[g][j]; sn[g][j] = wn[g] * sn[g][j] + sl[j] - pn[g][j];
+                    qp += sp[g][j] * sp[g][j]; qn += sn[g][j] * sn[g][j];
+                }
+                const T bpos = bp[g], bneg = bn[g];
+                const T x_uij = __shfl(-bpos + bneg, 0, 64) - wsum(qp) + wsum(qn);
+                deri[g] = sigm(x_uij);
+                if (lane == 0) {
+                    scat(beta + pos[g], lr * (-deri[g] - breg * bpos), bpos, at_bias && !hp[g]);   // [9]
+                    scat(beta + neg[g], lr * (deri[g] - breg * bneg), bneg, at_bias && !hn[g]);    // [10]
+                }
+            }
+            walk_history<RIF, EPL, T>(P, seq, fo, at_item ? m.hot : nullptr, K, lane, tmax, [&](int h, int c, const T (&x)[EPL], bool c_hot) {
+                T d[EPL]; int nact = 0;
+#pragma unroll
+                for (int j = 0; j < EPL; j++) d[j] = 0;
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    if (h >= tpos[g]) continue;
+                    uint64_t hit = __ballot(pathl[g] == c);
+                    const bool inpath = hit != 0;
+                    T se = 0;
+                    while (hit) { se += __shfl(etal[g], (int)__ffsll((unsigned long long)hit) - 1, 64); hit &= hit - 1; }
+                    T a, b;   // delta_g = deri * (a * dist_pos + b * dist_neg) - lambda * P_c
+                    if (inpath) {
+                        if (c != pos[g]) { if (c == neg[g]) continue; a = -(wp[g] + se); b = wn[g] + se; }   // [1]
+                        else { a = 1 - se; b = wn[g] + se; }                                                // [4]
+                    } else {
+                        if (c != pos[g]) { a = -wp[g]; b = c != neg[g] ? wn[g] : (T)-1; }                    // [2] / [7]
+                        else { a = 1; b = wn[g]; }                                                          // [5]
+                    }
+                    a *= deri[g]; b *= deri[g]; nact++;
+#pragma unroll
+                    for (int j = 0; j < EPL; j++) d[j] += a * sp[g][j] + b * sn[g][j];
+                }
+                if (nact == 0) return;
+                const bool atc = at_item && !c_hot;
+                T* row = P + (int64_t)c * K;
+                const T reg = lam * (T)nact;
 #pragma unroll
                 for (int j = 0; j < EPL; j++) {
                     const int k = lane + 64 * j;
-                    const T x = k < K ? P[(int64_t)c * K + k] : (T)0;
-                    sl[j] += e * x; proot[j] = x;
+                    if (k < K) scat(row + k, lr * (d[j] - reg * x[j]), x[j], atc);
                 }
-            }
-            T dp[EPL], dn[EPL]; T qp = 0, qn = 0;
+            });
 #pragma unroll
-            for (int j = 0; j < EPL; j++) {
-                dp[j] = wp * sp[j] + sl[j] - pp[j]; dn[j] = wn * sn[j] + sl[j] - pn[j];
-                qp += dp[j] * dp[j]; qn += dn[j] * dn[j];
-            }
-            T bpos = 0, bneg = 0;
-            if (lane == 0) { bpos = beta[pos]; bneg = beta[neg]; }
-            const T x_uij = __shfl(-bpos + bneg, 0, 64) - wsum(qp) + wsum(qn);
-            const T deri = sigm(x_uij);
-            if (lane == 0) {
-                scat(beta + pos, lr * (-deri - breg * bpos), bpos, at_bias && !m.hot[pos]);   // [9]
-                scat(beta + neg, lr * (deri - breg * bneg), bneg, at_bias && !m.hot[neg]);    // [10]
-            }
-            for (int h0 = 0; h0 < tpos; h0 += RIF) {
-                int it[RIF]; T x[RIF][EPL];
+            for (int g = 0; g < G; g++) {
+                if (g >= ng) continue;
+                const bool root = __shfl(pathl[g], 0, 64) == I;   // empty path -> the Root row, REBUS.cpp:414-418
+                const bool ap = at_item && !hp[g], an = at_item && !hn[g];
+                const bool pin = (pos_in >> g) & 1, nin = (neg_in >> g) & 1;
 #pragma unroll
-                for (int q = 0; q < RIF; q++) {
-                    it[q] = (h0 + q < tpos && fo[h0 + q]) ? seq[h0 + q] : -1;
-#pragma unroll
-                    for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; x[q][j] = (it[q] >= 0 && k < K) ? P[(int64_t)it[q] * K + k] : (T)0; }
+                for (int j = 0; j < EPL; j++) {
+                    const int k = lane + 64 * j;
+                    if (k >= K) continue;
+                    if (root) { const T pr = P[(int64_t)I * K + k]; scat(P + (int64_t)I * K + k, lr * (deri[g] * (-sp[g][j] + sn[g][j]) - lam * pr), pr, at_item); }   // [3]
+                    if (!nin) scat(P + (int64_t)neg[g] * K + k, lr * (deri[g] * (-sn[g][j]) - lam * pn[g][j]), pn[g][j], an);       // [8]
+                    if (!pin) scat(P + (int64_t)pos[g] * K + k, lr * (deri[g] * (sp[g][j]) - lam * pp[g][j]), pp[g][j], ap);        // [6]
                 }
-#pragma unroll
-                for (int q = 0; q < RIF; q++) {
-                    if (it[q] < 0) continue;
-                    const int c = it[q];
-                    bool inpath = false; T se = 0;
-                    for (int r = 0; r < np; r++) if (path[r] == c) { inpath = true; se += (T)etas[r]; }
-                    T a, b;   // delta = lr * (deri * (a * dist_pos + b * dist_neg) - lambda * P_c)
-                    if (inpath) {
-                        if (c != pos) { if (c == neg) continue; a = -(wp + se); b = wn + se; }   // [1]
-                        else { a = 1 - se; b = wn + se; }                                        // [4]
-                    } else {
-                        if (c != pos) { a = -wp; b = c != neg ? wn : (T)-1; }                    // [2] / [7]
-                        else { a = 1; b = wn; }                                                  // [5]
-                    }
-                    const bool atc = at_item && !m.hot[c];
-                    T* row = P + (int64_t)c * K;
-#pragma unroll
-                    for (int j = 0; j < EPL; j++) {
-                        const int k = lane + 64 * j;
-                        if (k < K) scat(row + k, lr * (deri * (a * dp[j] + b * dn[j]) - lam * x[q][j]), x[q][j], atc);
-                    }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < EPL; j++) {
-                const int k = lane + 64 * j;
-                if (k >= K) continue;
-                if (path[0] == I) scat(P + (int64_t)I * K + k, lr * (deri * (-dp[j] + dn[j]) - lam * proot[j]), proot[j], at_item);     // [3]
-                if (!neg_in) scat(P + (int64_t)neg * K + k, lr * (deri * (-dn[j]) - lam * pn[j]), pn[j], at_item && !m.hot[neg]);       // [8]
-                if (!pos_in) scat(P + (int64_t)pos * K + k, lr * (deri * (dp[j]) - lam * pp[j]), pp[j], at_item && !m.hot[pos]);        // [6]
             }
         }
+      }
     }
 
     if constexpr (MODEL == REC_FOSSIL || MODEL == REC_FOSSIL_SIMPLE) {
@@ -317,39 +409,61 @@ __global__ void apply_global_history_kernel(DevModel m, T lr, T cap)
     *w += lr / df * scale * (g - n * (T)m.lambda / df * (*w));
 }
 
-template <int MODEL, class T>
-static int launch_history(const DevModel& m, const int4* tuples, int64_t n, double lr, int atomic, int64_t max_in_flight, hipStream_t st)
+template <int MODEL, class T, int EPL, int G>
+int launch_g(const DevModel& m, const int4* tuples, int64_t n, double lr, int atomic, int64_t max_in_flight, hipStream_t st)
 {
-    // one tuple per wavefront at a time: the number of wavefronts launched is the number of tuples in flight
-    int64_t waves = n;
-    if (max_in_flight > 0 && waves > max_in_flight) waves = max_in_flight;
+    // one group per wavefront at a time: G tuples in flight per wavefront
+    int64_t waves = (n + G - 1) / G;
+    if (max_in_flight > 0 && waves > (max_in_flight + G - 1) / G) waves = (max_in_flight + G - 1) / G;
     int64_t blocks = (waves + 3) / 4;
     if (blocks > 2048) blocks = 2048;
-    const dim3 grid((unsigned)blocks), block(256);
-    if (m.K <= 64) hipLaunchKernelGGL((sgd_history_kernel<MODEL, T, 1>), grid, block, 0, st, m, tuples, n, (T)lr, atomic);
-    else if (m.K <= 128) hipLaunchKernelGGL((sgd_history_kernel<MODEL, T, 2>), grid, block, 0, st, m, tuples, n, (T)lr, atomic);
-    else hipLaunchKernelGGL((sgd_history_kernel<MODEL, T, 4>), grid, block, 0, st, m, tuples, n, (T)lr, atomic);
+    if ((n + G - 1) / G > 0x7fffffff - 64 * blocks) { rec_set_error("too many tuples in one launch"); return -1; }
+    HIP_TRY(hipMemsetAsync(m.work_counter, 0, sizeof(int), st));
+    hipLaunchKernelGGL((sgd_history_batch_kernel<MODEL, T, EPL, G>), dim3((unsigned)blocks), dim3(256), 0, st, m, tuples, n, (T)lr, atomic);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
+// the widest group the registers hold at this K that divides the sampler's batch
+template <int MODEL, class T>
+int launch_k(const DevModel& m, const int4* tuples, int64_t n, double lr, int atomic, int64_t max_in_flight, int batch, hipStream_t st)
+{
+    if (batch == 1) {
+        if (m.K <= 64) return launch_g<MODEL, T, 1, 1>(m, tuples, n, lr, atomic, max_in_flight, st);
+        if (m.K <= 128) return launch_g<MODEL, T, 2, 1>(m, tuples, n, lr, atomic, max_in_flight, st);
+        return launch_g<MODEL, T, 4, 1>(m, tuples, n, lr, atomic, max_in_flight, st);
+    }
+    if (m.K <= 64) {
+        if (batch % 8 == 0) return launch_g<MODEL, T, 1, 8>(m, tuples, n, lr, atomic, max_in_flight, st);
+        if (batch % 4 == 0) return launch_g<MODEL, T, 1, 4>(m, tuples, n, lr, atomic, max_in_flight, st);
+        return launch_g<MODEL, T, 1, 2>(m, tuples, n, lr, atomic, max_in_flight, st);
+    }
+    if (m.K <= 128) {
+        if (batch % 4 == 0) return launch_g<MODEL, T, 2, 4>(m, tuples, n, lr, atomic, max_in_flight, st);
+        return launch_g<MODEL, T, 2, 2>(m, tuples, n, lr, atomic, max_in_flight, st);
+    }
+    return launch_g<MODEL, T, 4, 2>(m, tuples, n, lr, atomic, max_in_flight, st);
+}
+
 template <class T>
-static int dispatch_history(const DevModel& m, const int4* tuples, int64_t n, double lr, int atomic, int64_t max_in_flight, hipStream_t st)
+int dispatch(const DevModel& m, const int4* tuples, int64_t n, double lr, int atomic, int64_t max_in_flight, int batch, hipStream_t st)
 {
     switch (m.model) {
-    case REC_FOSSIL: return launch_history<REC_FOSSIL, T>(m, tuples, n, lr, atomic, max_in_flight, st);
-    case REC_FOSSIL_SIMPLE: return launch_history<REC_FOSSIL_SIMPLE, T>(m, tuples, n, lr, atomic, max_in_flight, st);
-    case REC_REBUS: return launch_history<REC_REBUS, T>(m, tuples, n, lr, atomic, max_in_flight, st);
+    case REC_FOSSIL: return launch_k<REC_FOSSIL, T>(m, tuples, n, lr, atomic, max_in_flight, batch, st);
+    case REC_FOSSIL_SIMPLE: return launch_k<REC_FOSSIL_SIMPLE, T>(m, tuples, n, lr, atomic, max_in_flight, batch, st);
+    case REC_REBUS: return launch_k<REC_REBUS, T>(m, tuples, n, lr, atomic, max_in_flight, batch, st);
     default: rec_set_error("not a history model"); return -1;
     }
 }
+}  // namespace
 
 int launch_sgd_history(const DevModel& m, int precision, const int4* tuples, int64_t n, double lr, int atomic, int64_t max_in_flight,
-                       hipStream_t st)
+                               int batch, hipStream_t st)
 {
     if (n <= 0) return 0;
-    return precision == REC_F64 ? dispatch_history<double>(m, tuples, n, lr, atomic, max_in_flight, st)
-                                : dispatch_history<float>(m, tuples, n, lr, atomic, max_in_flight, st);
+    if (batch != 1 && batch != 2 && batch != 4 && batch != 8) { rec_set_error("user_batch must be 1, 2, 4 or 8"); return -1; }
+    return precision == REC_F64 ? dispatch<double>(m, tuples, n, lr, atomic, max_in_flight, batch, st)
+                                : dispatch<float>(m, tuples, n, lr, atomic, max_in_flight, batch, st);
 }
 
 int launch_apply_global_history(const DevModel& m, int precision, double lr, double cap, hipStream_t st)

@@ -55,7 +55,12 @@ __global__ void __launch_bounds__(256) sgd_hogwild_kernel(DevModel m, const int4
         }
         return p;
     };
-    auto load_rows = [&](const int4 (&tp)[B], T (&v)[B][R][EPL], T& bs) {
+    // hf: lane b*R+r of the group holds the hot flag of row r of tuple b when that row would otherwise be scattered
+    // with atomics; bias_hot: the same for the bias this lane holds.  The flags travel with the rows: asked for only when the scatter needs them, every one of them would cost the
+    // wavefront a memory round trip of its own, behind the prefetched rows.
+    auto load_rows = [&](const int4 (&tp)[B], T (&v)[B][R][EPL], T& bs, int& hf, uint8_t& bias_hot) {
+        static_assert(B * R <= LPT, "one lane of the group per row flag");
+        int flag_item = -1;   // lane b*R+r of the group fetches the flag of row r of tuple b
 #pragma unroll
         for (int b = 0; b < B; b++) {
             const bool ok = tp[b].x >= 0;
@@ -64,23 +69,33 @@ __global__ void __launch_bounds__(256) sgd_hogwild_kernel(DevModel m, const int4
                 int width; const T* row = row_ptr<MODEL, T>(m, tp[b], r, width);
 #pragma unroll
                 for (int j = 0; j < EPL; j++) { const int k = g + LPT * j; v[b][r][j] = (ok && k < width) ? row[k] : (T)0; }
+                if (g == b * R + r && ok && ((atomic >> r) & 1)) flag_item = row_item<MODEL>(tp[b], r);
             }
         }
-        bs = 0;
-        if constexpr (NB == 2) { const T* p = my_bias_ptr(tp); if (p) bs = *p; }
+        hf = flag_item >= 0 ? (int)m.hot[flag_item] : 0;
+        bs = 0; bias_hot = 0;
+        if constexpr (NB == 2) {
+            const T* p = my_bias_ptr(tp);
+            if (p) {
+                bs = *p;
+                if ((atomic >> 8) & 1) bias_hot = m.hot[p - (const T*)m.tab[MODEL == REC_BPRMF ? BPRMF_BETA : TR_BETA]];
+            }
+        }
     };
 
     int4 tp[B], tn[B];
     T v[B][R][EPL], bs;
+    int hf; uint8_t bias_hot;
     load_idx(gid, tp);
     load_idx(gid + ngroups, tn);
-    load_rows(tp, v, bs);
+    load_rows(tp, v, bs, hf, bias_hot);
     for (int64_t batch = gid; batch < nbatch; batch += ngroups) {
         // indices two batches ahead, rows one batch ahead
         int4 tnn[B];
         load_idx(batch + 2 * ngroups, tnn);
         T vn[B][R][EPL], bn;
-        load_rows(tn, vn, bn);
+        int hfn; uint8_t bias_hot_n;
+        load_rows(tn, vn, bn, hfn, bias_hot_n);
         // keep the values the plain-store mode adds its deltas to
         T old[B][R][EPL]; T mine = 0;  // mine: deri of the tuple whose bias this lane holds
         bool at[B][R];
@@ -94,8 +109,7 @@ __global__ void __launch_bounds__(256) sgd_hogwild_kernel(DevModel m, const int4
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 // rows of hot items fall back to plain stores: their atomics would serialize on one address
-                const int it = row_item<MODEL>(tp[b], r);
-                at[b][r] = ((atomic >> r) & 1) && !(tp[b].x >= 0 && it >= 0 && m.hot[it]);
+                at[b][r] = ((atomic >> r) & 1) && !__shfl(hf, b * R + r, LPT);
             }
             const T deri = step<MODEL, T, LPT, EPL>(m, lr, g, v[b], b0, b1, rg, racc, at[b]);
             if ((g >> 1) == b) mine = deri;
@@ -115,11 +129,10 @@ __global__ void __launch_bounds__(256) sgd_hogwild_kernel(DevModel m, const int4
             T* p = my_bias_ptr(tp);
             if (p) {
                 const T sgn = ((g & 1) == 0) == (MODEL == REC_BPRMF) ? (T)1 : (T)-1;
-                const T* base = (const T*)m.tab[MODEL == REC_BPRMF ? BPRMF_BETA : TR_BETA];
-                scatter(p, lr * (sgn * mine - (T)m.bias_reg * bs), bs, ((atomic >> 8) & 1) && !m.hot[p - base]);
+                scatter(p, lr * (sgn * mine - (T)m.bias_reg * bs), bs, ((atomic >> 8) & 1) && !bias_hot);
             }
         }
-        bs = bn;
+        bs = bn; bias_hot = bias_hot_n; hf = hfn;
 #pragma unroll
         for (int b = 0; b < B; b++) {
             tp[b] = tn[b]; tn[b] = tnn[b];

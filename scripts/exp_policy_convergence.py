@@ -31,16 +31,25 @@ def main():
     import torch
     seq_off, seq_item, test, val, _ = make_synthetic(args.users, args.items, args.clicks, 7, torch.device("cuda:0"))
     for var in args.variants.split(","):
-        mask = None
-        stale = None
-        if var.startswith("s"):   # s<n>: default policy with stale_window n
-            stale, var = int(var[1:]), "-1:0"
-        gwin = None
-        if var.startswith("g"):   # g<n>: default policy with global_window n
-            gwin, var = int(var[1:]), "-1:0"
-        if var.startswith("m"):   # m<hexmask>: hybrid policy's hot exemption with this atomic mask
-            mask, var = int(var[1:], 16), "1:0"
-        policy, group, *rest = (int(x) for x in var.split(":"))
+        # a variant is a '+'-joined list of: "<policy>:<group>[:run_hot:run_hot_atomic:run_shared]", p<policy>, s<stale_window>,
+        # g<global_window>, m<hex atomic mask on top of the hybrid policy>, u<user_batch>, h<hot_count>
+        mask = stale = gwin = ub = hotc = None
+        policy, group, rest = -1, 0, []
+        for tok in var.split("+"):
+            if tok[0] == "s":
+                stale = int(tok[1:])
+            elif tok[0] == "g":
+                gwin = int(tok[1:])
+            elif tok[0] == "m":
+                mask, policy = int(tok[1:], 16), 1
+            elif tok[0] == "u":
+                ub = int(tok[1:])
+            elif tok[0] == "h":
+                hotc = int(tok[1:])
+            elif tok[0] == "p":
+                policy = int(tok[1:])
+            else:
+                policy, group, *rest = (int(x) for x in tok.split(":"))
         po = pi = None
         if args.model == "REBUS":
             lo, li = ra.fsub_mine(args.items, seq_off, seq_item, args.l, 2)
@@ -56,6 +65,10 @@ def main():
             eng.set_option("global_window", gwin)
         if mask is not None:
             eng.set_option("atomic", mask)
+        if ub is not None:
+            eng.set_option("user_batch", ub)
+        if hotc is not None:
+            eng.set_option("hot_count", hotc)
         eng.set_option("chunk", args.chunk)
         for name, v in zip(("run_hot", "run_hot_atomic", "run_shared"), rest):
             eng.set_option(name, v)
@@ -74,7 +87,7 @@ def main():
         um, un = eng.kernel_stats(0)
         sm, sn = eng.kernel_stats(2)
         W = eng.download()
-        print(f"policy {policy} group {group} {rest} mask {mask} stale {stale} gwin {gwin}: " + " | ".join(line) + f"  finite={np.isfinite(W).all()} |W|max={np.abs(W).max():.2f} "
+        print(f"{var}: " + " | ".join(line) + f"  finite={np.isfinite(W).all()} |W|max={np.abs(W).max():.2f} "
               f"{t_train:.2f}s update {um / max(un, 1):.3f} ms x {un} sampler {sm / max(sn, 1):.3f} ms x {sn}", flush=True)
         eng.close()
 
