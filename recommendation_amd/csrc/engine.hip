@@ -292,6 +292,9 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     if (d->model == REC_TRANSREC || d->model == REC_TRANSREC_L1) e->global_window = 1 << 22;
     // scatter policy: exact sums for small problems, the hybrid for large ones (see rec_set_option)
     rec_set_option(e, "update_policy", e->steps_per_epoch >= (1 << 22) ? 1 : 0);
+    // REBUS walks a user's history once for two tuples (measured: 1.3x the throughput at equal or better validation
+    // AUC); for Fossil / FossilSimple pairs cost about 0.003 AUC in later epochs and stay an option.
+    e->user_batch = (d->model == REC_REBUS && e->steps_per_epoch >= (1 << 22)) ? 2 : 1;
     *out = e;
     return 0;
 }

@@ -37,31 +37,59 @@ template <class T> __device__ __forceinline__ T sigm(T x) { return (T)1 / ((T)1 
 template <class T> __device__ __forceinline__ T wsum(T v) { return group_sum<64>(v); }
 
 // Walks the rows tab[seq[h]] for h in [0, hend) (only positions with first[h] set when `first` is given), RIF rows
-// per round, and calls body(h, item, row components of this lane).  The rows of round r+1 are requested before
-// the body of round r runs: memory operations retire in order on a wavefront, so a body that ends in atomics
-// would otherwise make the next round's loads wait for those atomics to come back.  A row that round r updates
-// and round r+1 reads again (a repeated item) is therefore read before its update.
-template <int RIF, int EPL, class T, class Body>
-__device__ __forceinline__ void walk_history(const T* tab, const int32_t* seq, const uint8_t* first, const uint8_t* hot, int K, int lane,
-                                             int hend, Body body)
+// per round.  body(h, item, row components of this lane, delta out) is called for every row; when it returns true
+// and SCATTER is set, the row is updated by the delta (float atomics, or plain stores for hot items / !at_item).
+//
+// Memory operations retire in order on a wavefront, and a wait for one of them is a wait for everything issued
+// before it.  So a round is laid out as: request the rows (and hot flags) of the next round; request the item
+// ids of the round after that (one load: lane q fetches position h0+q, the ids are read back lane by lane);
+// compute the deltas of this round's rows from registers; issue this round's scatters back to back.  Nothing a
+// scatter needs comes from a load that is younger than the previous round's scatters.
+// A row that round r updates and round r+1 reads again (a repeated item) is read before its update.
+template <int RIF, int EPL, bool SCATTER, class T, class Body>
+__device__ __forceinline__ void walk_history(T* tab, const int32_t* seq, const uint8_t* first, const uint8_t* hot, int K, int lane,
+                                             int hend, bool at_item, Body body)
 {
+    static_assert(RIF <= 64, "one lane per position of a round");
+    auto load_ids = [&](int h0) {
+        const int h = h0 + lane;
+        int id = -1, keep = 1;
+        if (lane < RIF && h < hend) { id = seq[h]; if (first) keep = first[h]; }
+        return keep ? id : -1;
+    };
     int itA[RIF], itB[RIF], hotA[RIF], hotB[RIF]; T xA[RIF][EPL], xB[RIF][EPL];
-    auto load = [&](int h0, int (&it)[RIF], int (&hf)[RIF], T (&x)[RIF][EPL]) {
+    auto load_rows = [&](int ids, int (&it)[RIF], int (&hf)[RIF], T (&x)[RIF][EPL]) {
 #pragma unroll
         for (int q = 0; q < RIF; q++) {
-            const int h = h0 + q;
-            it[q] = (h < hend && (!first || uni((int)first[h]))) ? uni(seq[h]) : -1;
+            it[q] = __builtin_amdgcn_readlane(ids, q);
 #pragma unroll
             for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; x[q][j] = (it[q] >= 0 && k < K) ? tab[(int64_t)it[q] * K + k] : (T)0; }
-            // the item's hot flag travels with its row: fetched when the scatter needs it, it would cost a round trip per row
-            hf[q] = (hot && it[q] >= 0) ? (int)hot[it[q]] : 0;
+            hf[q] = (SCATTER && hot && it[q] >= 0) ? (int)hot[it[q]] : 0;
         }
     };
-    load(0, itA, hotA, xA);
+    int idsB = load_ids(0);
+    load_rows(idsB, itA, hotA, xA);
+    idsB = load_ids(RIF);
     for (int h0 = 0; h0 < hend; h0 += RIF) {
-        load(h0 + RIF, itB, hotB, xB);
+        load_rows(idsB, itB, hotB, xB);
+        idsB = load_ids(h0 + 2 * RIF);
+        T d[RIF][EPL]; bool upd[RIF];
 #pragma unroll
-        for (int q = 0; q < RIF; q++) { if (itA[q] >= 0) body(h0 + q, itA[q], xA[q], hotA[q] != 0); }
+        for (int q = 0; q < RIF; q++) {
+#pragma unroll
+            for (int j = 0; j < EPL; j++) d[q][j] = 0;
+            upd[q] = itA[q] >= 0 && body(h0 + q, itA[q], xA[q], d[q]);
+        }
+        if constexpr (SCATTER) {
+#pragma unroll
+            for (int q = 0; q < RIF; q++) {
+                if (!upd[q]) continue;
+                T* row = tab + (int64_t)itA[q] * K;
+                const bool atc = at_item && !hotA[q];
+#pragma unroll
+                for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; if (k < K) scat(row + k, d[q][j], xA[q][j], atc); }
+            }
+        }
 #pragma unroll
         for (int q = 0; q < RIF; q++) {
             itA[q] = itB[q]; hotA[q] = hotB[q];
@@ -134,7 +162,7 @@ __global__ void __launch_bounds__(256) sgd_history_batch_kernel(DevModel m, cons
             int cp[G], cn[G];
 #pragma unroll
             for (int g = 0; g < G; g++) cp[g] = cn[g] = 0;
-            walk_history<RIF, EPL, T>(Ui, seq, nullptr, nullptr, K, lane, nu, [&](int, int c, const T (&x)[EPL], bool) {
+            walk_history<RIF, EPL, false>(Ui, seq, nullptr, nullptr, K, lane, nu, false, [&](int, int c, const T (&x)[EPL], T (&)[EPL]) {
 #pragma unroll
                 for (int g = 0; g < G; g++) {
                     const bool a = c != pos[g], b = c != neg[g];
@@ -142,6 +170,7 @@ __global__ void __launch_bounds__(256) sgd_history_batch_kernel(DevModel m, cons
 #pragma unroll
                     for (int j = 0; j < EPL; j++) { sp[g][j] += a ? x[j] : (T)0; sn[g][j] += b ? x[j] : (T)0; }
                 }
+                return false;
             });
             // short-term weights: lane ind holds WT[ind] + WTu[u][ind] (Fossil) / lane 0 alpha + alpha_u[u] (FossilSimple)
             T wt_g = 0, wt_u = 0;
@@ -204,10 +233,7 @@ __global__ void __launch_bounds__(256) sgd_history_batch_kernel(DevModel m, cons
             // pass 2: every history row once for the whole group, Fossil.cpp:209-247 / FossilSimple.cpp:198-226
             const T wt0 = __shfl(wt, 0, 64);
             const T reg = lam * (T)ng;
-            walk_history<RIF, EPL, T>(Ui, seq, nullptr, at_item ? m.hot : nullptr, K, lane, nu, [&](int, int c, const T (&x)[EPL], bool c_hot) {
-                T d[EPL];
-#pragma unroll
-                for (int j = 0; j < EPL; j++) d[j] = 0;
+            walk_history<RIF, EPL, true>(Ui, seq, nullptr, at_item ? m.hot : nullptr, K, lane, nu, at_item, [&](int, int c, const T (&x)[EPL], T (&d)[EPL]) {
 #pragma unroll
                 for (int g = 0; g < G; g++) {
                     const uint64_t hit = __ballot(prevl[g] == c);
@@ -222,13 +248,9 @@ __global__ void __launch_bounds__(256) sgd_history_batch_kernel(DevModel m, cons
 #pragma unroll
                     for (int j = 0; j < EPL; j++) d[j] += cpz * vp[g][j] - cnz * vn[g][j];
                 }
-                const bool atc = at_item && !c_hot;
-                T* row = Ui + (int64_t)c * K;
 #pragma unroll
-                for (int j = 0; j < EPL; j++) {
-                    const int k = lane + 64 * j;
-                    if (k < K) scat(row + k, lr * (d[j] - reg * x[j]), x[j], atc);
-                }
+                for (int j = 0; j < EPL; j++) d[j] = lr * (d[j] - reg * x[j]);
+                return true;
             });
             // Fossil.cpp:249-252
 #pragma unroll
@@ -279,7 +301,7 @@ __global__ void __launch_bounds__(256) sgd_history_batch_kernel(DevModel m, cons
             int cp[G], cn[G]; unsigned pos_in = 0, neg_in = 0;
 #pragma unroll
             for (int g = 0; g < G; g++) cp[g] = cn[g] = 0;
-            walk_history<RIF, EPL, T>(P, seq, fo, nullptr, K, lane, tmax, [&](int h, int c, const T (&x)[EPL], bool) {
+            walk_history<RIF, EPL, false>(P, seq, fo, nullptr, K, lane, tmax, false, [&](int h, int c, const T (&x)[EPL], T (&)[EPL]) {
 #pragma unroll
                 for (int g = 0; g < G; g++) {
                     const bool in = h < tpos[g];
@@ -290,6 +312,7 @@ __global__ void __launch_bounds__(256) sgd_history_batch_kernel(DevModel m, cons
 #pragma unroll
                     for (int j = 0; j < EPL; j++) { sp[g][j] += a ? x[j] : (T)0; sn[g][j] += b ? x[j] : (T)0; }
                 }
+                return false;
             });
             T wp[G], wn[G], deri[G];
             T bp[G], bn[G];     // lane 0: the biases as the group found them
@@ -322,10 +345,8 @@ __global__ void __launch_bounds__(256) sgd_history_batch_kernel(DevModel m, cons
                     scat(beta + neg[g], lr * (deri[g] - breg * bneg), bneg, at_bias && !hn[g]);    // [10]
                 }
             }
-            walk_history<RIF, EPL, T>(P, seq, fo, at_item ? m.hot : nullptr, K, lane, tmax, [&](int h, int c, const T (&x)[EPL], bool c_hot) {
-                T d[EPL]; int nact = 0;
-#pragma unroll
-                for (int j = 0; j < EPL; j++) d[j] = 0;
+            walk_history<RIF, EPL, true>(P, seq, fo, at_item ? m.hot : nullptr, K, lane, tmax, at_item, [&](int h, int c, const T (&x)[EPL], T (&d)[EPL]) {
+                int nact = 0;
 #pragma unroll
                 for (int g = 0; g < G; g++) {
                     if (h >= tpos[g]) continue;
@@ -345,15 +366,11 @@ __global__ void __launch_bounds__(256) sgd_history_batch_kernel(DevModel m, cons
 #pragma unroll
                     for (int j = 0; j < EPL; j++) d[j] += a * sp[g][j] + b * sn[g][j];
                 }
-                if (nact == 0) return;
-                const bool atc = at_item && !c_hot;
-                T* row = P + (int64_t)c * K;
+                if (nact == 0) return false;
                 const T reg = lam * (T)nact;
 #pragma unroll
-                for (int j = 0; j < EPL; j++) {
-                    const int k = lane + 64 * j;
-                    if (k < K) scat(row + k, lr * (d[j] - reg * x[j]), x[j], atc);
-                }
+                for (int j = 0; j < EPL; j++) d[j] = lr * (d[j] - reg * x[j]);
+                return true;
             });
 #pragma unroll
             for (int g = 0; g < G; g++) {

@@ -76,18 +76,22 @@ def main():
         eng.init_params(seed=1)
         t0 = time.perf_counter()
         line = []
+        best = (0.0, 0.0, 0.0, 0)   # validation AUC, test AUC and HIT@50 at that epoch, epoch: what the reference's early stopping keeps
         for ep in range(args.epochs):
             eng.sgd_epoch(args.lr, eng.steps_per_epoch, seed=5, epoch=ep)
             if (ep + 1) % args.every == 0:
                 eng.sync()
                 m = eng.eval()[0]
-                line.append(f"ep{ep + 1}: val {m.auc_val:.4f} test {m.auc_test:.4f} hit {m.hit_test:.4f}")
+                if m.auc_val > best[0]:
+                    best = (m.auc_val, m.auc_test, m.hit_test, ep + 1)
+                if args.every > 1 or (ep + 1) % 5 == 0:
+                    line.append(f"ep{ep + 1}: val {m.auc_val:.4f} test {m.auc_test:.4f} hit {m.hit_test:.4f}")
         eng.sync()
         t_train = time.perf_counter() - t0
         um, un = eng.kernel_stats(0)
         sm, sn = eng.kernel_stats(2)
         W = eng.download()
-        print(f"{var}: " + " | ".join(line) + f"  finite={np.isfinite(W).all()} |W|max={np.abs(W).max():.2f} "
+        print(f"{var}: best val {best[0]:.4f} -> test {best[1]:.4f} hit {best[2]:.4f} @ep{best[3]} | " + " | ".join(line) + f"  finite={np.isfinite(W).all()} |W|max={np.abs(W).max():.2f} "
               f"{t_train:.2f}s update {um / max(un, 1):.3f} ms x {un} sampler {sm / max(sn, 1):.3f} ms x {sn}", flush=True)
         eng.close()
 
