@@ -180,6 +180,9 @@ int rec_table_info(const rec_engine* e, int t, void** dev_ptr, int64_t* rows, in
  *                   scattered with atomics (default 128, 32, 0)
  *   "chunk"         tuples sampled per sampler launch (default 2^26)
  *   "overlap"       1 = sample chunk c+1 on a second stream while chunk c is applied (default 0: measured slower)
+ *   "user_batch"    Fossil / FossilSimple / REBUS: 1, 2, 4 or 8 consecutive steps of an epoch share their user draw and one
+ *                   wavefront walks that user's history once for all of them (default 2 for REBUS, else 1);
+ *                   rec_sgd_replay in Hogwild mode then expects its tuples grouped the same way
  *   "stale_window"  tuples per update launch for small catalogs (0 = no limit)
  *   "global_window" tuples per update launch for models with a row every tuple touches
  *   "global_cap"    such a row moves by at most this many steps' worth of learning rate per launch
