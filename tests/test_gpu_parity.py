@@ -465,6 +465,32 @@ def test_hogwild_epoch_moves_towards_the_data(model):
         e.close()
 
 
+@pytest.mark.parametrize("G", [2, 8])
+@pytest.mark.parametrize("model", ["FossilSimple", "Fossil", "REBUS"])
+def test_user_batched_epochs_train(model, G):
+    """Device epochs with user_batch G (chunks and global-row launches cut on group boundaries, the last
+    group of a launch short) keep the parameters finite and improve the validation AUC of the toy corpus."""
+    g, model, co, ci, labels = fixture_case(model, "toy")
+    e = make_engine(g, model, co, ci, labels, F32)
+    e.set_option("user_batch", G)
+    e.set_option("chunk", 1001)          # not a multiple of G: rounded up inside
+    e.set_option("global_window", 333)
+    e.init_params(3)
+    m0, _, _ = e.eval()
+    n = e.steps_per_epoch + 3
+    for ep in range(30):
+        e.sgd_epoch(0.05, n, seed=11, epoch=ep)
+    e.sync()
+    assert e.tuples_drawn == 30 * n
+    W = e.download()
+    assert np.isfinite(W).all()
+    m1, counts, _ = e.eval()
+    assert m1.auc_val > m0.auc_val, (model, G, m0.auc_val, m1.auc_val)
+    _, ref = make_oracle(g, model, co, ci, labels).eval(W)
+    assert np.array_equal(counts, ref)
+    e.close()
+
+
 @pytest.mark.parametrize("model", TOY_MODELS)
 def test_sampler_support(model):
     """Every drawn tuple lies in the support of the reference's sampler for that model."""
