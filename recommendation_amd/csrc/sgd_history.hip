@@ -17,6 +17,7 @@
 // address): Fossil's global weights WT[0..L) and FossilSimple's alpha collect their gradient sums
 // per block and are folded in by launch_apply_global_history after the launch; they stay constant
 // during a launch.
+#include <algorithm>
 #include "common.h"
 
 namespace {
@@ -100,7 +101,7 @@ __device__ __forceinline__ void walk_history(T* tab, const int32_t* seq, const u
 }
 
 template <int MODEL, class T, int EPL, int G>
-__global__ void __launch_bounds__(256) sgd_history_batch_kernel(DevModel m, const int4* __restrict__ tuples, int64_t n, T lr, int atomic)
+__global__ void __launch_bounds__(256) sgd_history_batch_kernel(DevModel m, const int4* __restrict__ tuples, int64_t n, T lr, int atomic, int CLAIM)
 {
     constexpr int RIF = EPL == 1 ? 8 : 4;   // history rows per round
     const int lane = threadIdx.x & 63;
@@ -112,10 +113,8 @@ __global__ void __launch_bounds__(256) sgd_history_batch_kernel(DevModel m, cons
     T gsum = 0, gcnt = 0;   // Fossil: lane ind collects WT[ind]'s gradient; FossilSimple: lane 0 alpha's
 
     // Groups are claimed from a counter, CLAIM at a time: a group's work is proportional to the length of its
-    // user's history, which varies too much for a fixed assignment of groups to wavefronts to balance.  (One
-    // claim per tuple would make the counter the bottleneck: atomics on one address retire about 16 ns apart.)
+    // user's history, which varies too much for a fixed assignment of groups to wavefronts to balance.
     // The claim that follows is issued before the claimed groups' work and read after it.
-    constexpr int CLAIM = G >= 8 ? 1 : 8 / G;
     int next = 0;
     if (lane == 0) next = atomicAdd(m.work_counter, 1);
     for (;;) {
@@ -436,7 +435,11 @@ int launch_g(const DevModel& m, const int4* tuples, int64_t n, double lr, int at
     if (blocks > 2048) blocks = 2048;
     if ((n + G - 1) / G > 0x7fffffff - 64 * blocks) { rec_set_error("too many tuples in one launch"); return -1; }
     HIP_TRY(hipMemsetAsync(m.work_counter, 0, sizeof(int), st));
-    hipLaunchKernelGGL((sgd_history_batch_kernel<MODEL, T, EPL, G>), dim3((unsigned)blocks), dim3(256), 0, st, m, tuples, n, (T)lr, atomic);
+    // groups per claim: few enough claims that the counter is not the bottleneck (atomics on one address retire about
+    // 16 ns apart: measured 62.7 ms per 4M single-tuple claims), enough claims per wavefront that the launch ends evenly
+    const int64_t per_wave = (n + G - 1) / G / (16 * 4 * blocks);
+    const int claim = (int)std::min<int64_t>(std::max<int64_t>(per_wave, 1), G >= 8 ? 1 : 8 / G);
+    hipLaunchKernelGGL((sgd_history_batch_kernel<MODEL, T, EPL, G>), dim3((unsigned)blocks), dim3(256), 0, st, m, tuples, n, (T)lr, atomic, claim);
     HIP_TRY(hipGetLastError());
     return 0;
 }
