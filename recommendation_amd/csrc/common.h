@@ -36,7 +36,10 @@ struct DevModel {
     void* gacc;                         // accumulators for rows every tuple touches (TransRec r, Fossil WT, FossilSimple alpha)
     const int32_t* eval_users;          // users of this engine's shard that have a test item
     int n_eval;
-    const uint32_t* neg_filter;         // [U or I][16] 512-bit membership filter of the set a drawn negative must avoid (clicked items; MC: successors)
+    // [U or I][16] one 64-byte record per sampling owner (user; MC: source item), so that a draw touches one line for all
+    // of it: words 0-1 the owner's offset in seq_item (MC: succ_item), word 2 its length there, words 4-15 a 384-bit
+    // membership filter of the set a drawn negative must avoid (clicked items; MC: successors; all clear when unused)
+    const uint32_t* owner_rec;
     const int4* ev;                     // [n_ev] sampling events ordered by positive item: (owner, aux, positive, -), see launch_event_sampler
     const float* ev_w;                  // [n_ev] 1 / (number of events of the owner)
     int64_t n_ev;
@@ -151,15 +154,15 @@ __device__ __forceinline__ uint4 philox4x32(uint4 ctr, uint2 key)
 // uniform integer in [0, n) from 32 random bits (multiply-shift)
 __device__ __forceinline__ uint32_t bounded(uint32_t r, uint32_t n) { return __umulhi(r, n); }
 
-// is `x` in the sorted array a[0..n) ?
-// One-hash 512-bit filter in front of a sorted set: a clear bit proves absence with one load
-__host__ __device__ __forceinline__ uint32_t filter_slot(int32_t item) { return ((uint32_t)item * 2654435761u) >> 23; }
-__device__ __forceinline__ bool filter_may_contain(const uint32_t* __restrict__ f, int owner, int32_t item)
+// One-hash 384-bit filter in front of a sorted set: a clear bit proves absence with one load
+__host__ __device__ __forceinline__ uint32_t filter_slot(int32_t item) { return (uint32_t)(((uint64_t)((uint32_t)item * 2654435761u) * 384u) >> 32); }
+__device__ __forceinline__ bool filter_may_contain(const uint32_t* __restrict__ rec, int owner, int32_t item)
 {
     const uint32_t h = filter_slot(item);
-    return (f[(int64_t)owner * 16 + (h >> 5)] >> (h & 31)) & 1u;
+    return (rec[(int64_t)owner * 16 + 4 + (h >> 5)] >> (h & 31)) & 1u;
 }
 
+// is `x` in the sorted array a[0..n) ?
 __device__ __forceinline__ bool sorted_contains(const int32_t* a, int n, int32_t x)
 {
     int lo = 0, hi = n;

@@ -186,17 +186,23 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
             if (ok) elig.push_back(u);
         }
     }
-    // filter in front of the set a negative is tested against (sampler.hip)
-    std::vector<uint32_t> neg_filter;
-    if (d->model == REC_BPRMF || d->model == REC_TRANSREC || d->model == REC_TRANSREC_L1 || d->model == REC_MC) {
+    // per-owner sampling record (common.h): where the owner's events are, and the filter in front of the set a negative
+    // is tested against (sampler.hip)
+    std::vector<uint32_t> owner_rec;
+    {
         const bool mc = d->model == REC_MC;
+        const bool filtered = d->model == REC_BPRMF || d->model == REC_TRANSREC || d->model == REC_TRANSREC_L1 || mc;
         const int owners = mc ? I : U;
-        neg_filter.assign((size_t)owners * 16, 0u);
+        owner_rec.assign((size_t)owners * 16, 0u);
         for (int o = 0; o < owners; o++) {
+            uint32_t* r = &owner_rec[(size_t)o * 16];
+            const int64_t off = mc ? succ_off[o] : seq_off[o], len = (mc ? succ_off[o + 1] : seq_off[o + 1]) - off;
+            r[0] = (uint32_t)off; r[1] = (uint32_t)((uint64_t)off >> 32); r[2] = (uint32_t)len;
+            if (!filtered) continue;
             const int64_t b0 = mc ? sset_off[o] : clk_off[o], b1 = mc ? sset_off[o + 1] : clk_off[o + 1];
             for (int64_t p = b0; p < b1; p++) {
                 const uint32_t h = filter_slot(mc ? sset_item[p] : clk_item[p]);
-                neg_filter[(size_t)o * 16 + (h >> 5)] |= 1u << (h & 31);
+                r[4 + (h >> 5)] |= 1u << (h & 31);
             }
         }
     }
@@ -223,7 +229,7 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
 #define UP(vec, field) if (!rc) rc = upload(e, vec, &m.field)
     UP(seq_off, seq_off); UP(seq_item, seq_item); UP(test_item, test_item); UP(val_item, val_item);
     UP(clk_off, clk_off); UP(clk_item, clk_item); UP(first_occ, first_occ); UP(elig, elig); UP(eval_users, eval_users);
-    UP(train_count, train_count); UP(eta, eta); UP(neg_filter, neg_filter);
+    UP(train_count, train_count); UP(eta, eta); UP(owner_rec, owner_rec);
     if (d->model == REC_MC) { UP(succ_off, succ_off); UP(succ_item, succ_item); UP(sset_off, sset_off); UP(sset_item, sset_item); }
     if (d->model == REC_REBUS && !rc) {
         const int64_t nctx = E + 2 * (int64_t)U;

@@ -39,18 +39,25 @@ __global__ void __launch_bounds__(256) sampler_kernel(DevModel m, int4* __restri
     int4 t = make_int4(e, 0, 0, 0);
     if constexpr (MODEL == REC_MC) {
         // MC.cpp:80-89, 139-147: source item with successors, a successor, a non-successor
-        const int64_t a = m.succ_off[e]; const int cnt = (int)(m.succ_off[e + 1] - a);
+        const uint4 rec = *reinterpret_cast<const uint4*>(m.owner_rec + (int64_t)e * 16);
+        const int64_t a = (int64_t)(((uint64_t)rec.y << 32) | rec.x); const int cnt = (int)rec.z;
         const int pos = m.succ_item[a + bounded(rng.next(), (uint32_t)cnt)];
-        const int32_t* ss = m.sset_item + m.sset_off[e]; const int ns = (int)(m.sset_off[e + 1] - m.sset_off[e]);
+        // the successor set is only consulted when the filter cannot rule the candidate out
+        auto successor = [&](int item) {
+            if (!filter_may_contain(m.owner_rec, e, item)) return false;
+            const int64_t s0 = m.sset_off[e];
+            return sorted_contains(m.sset_item + s0, (int)(m.sset_off[e + 1] - s0), item);
+        };
         int neg = 0;
-        for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (!filter_may_contain(m.neg_filter, e, neg) || !sorted_contains(ss, ns, neg)) break; }
+        for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (!successor(neg)) break; }
         t = make_int4(e, pos, neg, 0);
     } else {
-        const int64_t so = m.seq_off[e]; const int nu = (int)(m.seq_off[e + 1] - so);
+        const uint4 rec = *reinterpret_cast<const uint4*>(m.owner_rec + (int64_t)e * 16);
+        const int64_t so = (int64_t)(((uint64_t)rec.y << 32) | rec.x); const int nu = (int)rec.z;
         const int32_t* seq = m.seq_item + so;
         // the clicked list is only consulted when the filter cannot rule the candidate out
         auto clicked = [&](int item) {
-            if (!filter_may_contain(m.neg_filter, e, item)) return false;
+            if (!filter_may_contain(m.owner_rec, e, item)) return false;
             const int64_t c0 = m.clk_off[e];
             return sorted_contains(m.clk_item + c0, (int)(m.clk_off[e + 1] - c0), item);
         };
@@ -242,11 +249,11 @@ __global__ void __launch_bounds__(256) event_emit_kernel(DevModel m, int4* __res
         int4 t;
         if constexpr (MODEL == REC_BPRMF) {
             const int32_t* clk = m.clk_item + m.clk_off[ev.x]; const int nc = (int)(m.clk_off[ev.x + 1] - m.clk_off[ev.x]);
-            for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (!filter_may_contain(m.neg_filter, ev.x, neg) || !sorted_contains(clk, nc, neg)) break; }
+            for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (!filter_may_contain(m.owner_rec, ev.x, neg) || !sorted_contains(clk, nc, neg)) break; }
             t = make_int4(ev.x, ev.z, neg, 0);
         } else if constexpr (MODEL == REC_MC) {
             const int32_t* ss = m.sset_item + m.sset_off[ev.x]; const int ns = (int)(m.sset_off[ev.x + 1] - m.sset_off[ev.x]);
-            for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (!filter_may_contain(m.neg_filter, ev.x, neg) || !sorted_contains(ss, ns, neg)) break; }
+            for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (!filter_may_contain(m.owner_rec, ev.x, neg) || !sorted_contains(ss, ns, neg)) break; }
             t = make_int4(ev.x, ev.z, neg, 0);
         } else {
             for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (neg != ev.z) break; }
