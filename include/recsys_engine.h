@@ -180,6 +180,8 @@ int rec_table_info(const rec_engine* e, int t, void** dev_ptr, int64_t* rows, in
  *                   scattered with atomics (default 128, 32, 0)
  *   "chunk"         tuples sampled per sampler launch (default 2^26)
  *   "overlap"       1 = sample chunk c+1 on a second stream while chunk c is applied (default 0: measured slower)
+ *   "event_phases"  event-major sampler only, before its first use: n > 0 orders the events by n item ranges of equal weight,
+ *                   shuffled inside a range (experiment knob: how much item locality in time the SGD tolerates)
  *   "user_batch"    Fossil / FossilSimple / REBUS: 1, 2, 4 or 8 consecutive steps of an epoch share their user draw and one
  *                   wavefront walks that user's history once for all of them (default 2 for REBUS, else 1);
  *                   rec_sgd_replay in Hogwild mode then expects its tuples grouped the same way

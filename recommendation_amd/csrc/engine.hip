@@ -46,6 +46,7 @@ struct rec_engine {
     int profile = 0;
     RunPolicy run_policy = {128, 32, 0};
     int64_t run_segment = 0;  // batches per lane group in the run-combining kernel (0 = automatic)
+    int event_phases = 0; // event-major sampler: > 0 = events ordered by that many item ranges of equal weight, shuffled inside a range
     int user_batch = 1;  // consecutive steps of an epoch that share their user draw (history models)
     int group = 0;       // 1: run-combining update kernel on the tuples as they come; 2: also sample by event, which yields chunks grouped by positive item
     // hip-event statistics: 0 update, 1 score, 2 sampler, 3 unused
@@ -482,14 +483,17 @@ static int ensure_events(rec_engine* e)
     // at the same moment, launch after launch.
     uint64_t x64 = 0x2545F4914F6CDD1Dull;
     auto rnd = [&](uint64_t bound) { x64 ^= x64 << 13; x64 ^= x64 >> 7; x64 ^= x64 << 17; return (x64 >> 11) % bound; };
-    int64_t b0 = 0;
-    for (int i = 0; i < I; i++) {   // start[i] is now the end of item i's events
-        const int64_t b1 = start[i];
+    auto shuffle = [&](int64_t b0, int64_t b1) {
         for (int64_t k = b1 - 1; k > b0; k--) {
             const int64_t j = b0 + (int64_t)rnd((uint64_t)(k - b0 + 1));
             std::swap(ev[k], ev[j]); std::swap(ev_w[k], ev_w[j]);
         }
-        b0 = b1;
+    };
+    if (e->event_phases > 0) {
+        for (int p = 0; p < e->event_phases; p++) shuffle(total * p / e->event_phases, total * (p + 1) / e->event_phases);
+    } else {
+        int64_t b0 = 0;
+        for (int i = 0; i < I; i++) { shuffle(b0, start[i]); b0 = start[i]; }   // start[i] is now the end of item i's events
     }
     if (int rc = upload(e, ev, &m.ev)) return rc;
     if (int rc = upload(e, ev_w, &m.ev_w)) return rc;
@@ -833,6 +837,7 @@ extern "C" int rec_set_option(rec_engine* e, const char* name, int64_t value)
     else if (s == "run_shared") { if (value < 1) { rec_set_error("run_shared must be positive"); return -1; } e->run_policy.shared = (int)value; }
     else if (s == "run_hot") { if (value < 1) { rec_set_error("run_hot must be positive"); return -1; } e->run_policy.hot = (int)value; }
     else if (s == "run_hot_atomic") e->run_policy.hot_atomic = value != 0;
+    else if (s == "event_phases") { if (value < 0 || e->dm.n_ev > 0) { rec_set_error("event_phases must be >= 0 and set before the first event-major epoch"); return -1; } e->event_phases = (int)value; }
     else if (s == "user_batch") { if (value != 1 && value != 2 && value != 4 && value != 8) { rec_set_error("user_batch must be 1, 2, 4 or 8"); return -1; } e->user_batch = (int)value; }
     else if (s == "run_segment") { if (value < 0) { rec_set_error("run_segment must be >= 0"); return -1; } e->run_segment = value; }
     else if (s == "group_by_item") { if (value < 0 || value > 3) { rec_set_error("group_by_item must be 0..3"); return -1; } e->group = (int)value; }

@@ -33,7 +33,7 @@ def main():
     for var in args.variants.split(","):
         # a variant is a '+'-joined list of: "<policy>:<group>[:run_hot:run_hot_atomic:run_shared]", p<policy>, s<stale_window>,
         # g<global_window>, m<hex atomic mask on top of the hybrid policy>, u<user_batch>, h<hot_count>
-        mask = stale = gwin = ub = hotc = None
+        mask = stale = gwin = ub = hotc = phases = None
         policy, group, rest = -1, 0, []
         for tok in var.split("+"):
             if tok[0] == "s":
@@ -46,6 +46,8 @@ def main():
                 ub = int(tok[1:])
             elif tok[0] == "h":
                 hotc = int(tok[1:])
+            elif tok[0] == "e":
+                phases = int(tok[1:])
             elif tok[0] == "p":
                 policy = int(tok[1:])
             else:
@@ -69,6 +71,8 @@ def main():
             eng.set_option("user_batch", ub)
         if hotc is not None:
             eng.set_option("hot_count", hotc)
+        if phases is not None:
+            eng.set_option("event_phases", phases)
         eng.set_option("chunk", args.chunk)
         for name, v in zip(("run_hot", "run_hot_atomic", "run_shared"), rest):
             eng.set_option(name, v)
