@@ -291,7 +291,7 @@ def main():
             if name.startswith("sgd_runs_kernel" if grouped else "sgd_hogwild_kernel") and "hbm_traffic_bytes_per_launch" in e and \
                     abs(e.get("tuples_per_launch", 0) - tuples_per_launch) < 0.01 * tuples_per_launch:
                 traffic = int(e["hbm_traffic_bytes_per_launch"])
-    roofline = {"bound": "hbm", "kernel": "sgd_history_kernel" if args.model in ("Fossil", "FossilSimple", "REBUS") else "sgd_runs_kernel" if grouped else "sgd_hogwild_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+    roofline = {"bound": "hbm", "kernel": "sgd_history_batch_kernel" if args.model in ("Fossil", "FossilSimple", "REBUS") else "sgd_runs_kernel" if grouped else "sgd_hogwild_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "bytes_per_triple": bytes_per_triple, "tuples_per_launch": int(tuples_per_launch),
                 "avg_launch_ms": round(avg_ms, 4), "launches": int(upd_n),
