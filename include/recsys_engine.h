@@ -183,7 +183,7 @@ int rec_table_info(const rec_engine* e, int t, void** dev_ptr, int64_t* rows, in
  *   "event_phases"  event-major sampler only, before its first use: n > 0 orders the events by n item ranges of equal weight,
  *                   shuffled inside a range (experiment knob: how much item locality in time the SGD tolerates)
  *   "user_batch"    Fossil / FossilSimple / REBUS: 1, 2, 4 or 8 consecutive steps of an epoch share their user draw and one
- *                   wavefront walks that user's history once for all of them (default 2 for REBUS, else 1);
+ *                   wavefront walks that user's history once for all of them (default 2 when an epoch is >= 4M steps, else 1);
  *                   rec_sgd_replay in Hogwild mode then expects its tuples grouped the same way
  *   "stale_window"  tuples per update launch for small catalogs (0 = no limit)
  *   "global_window" tuples per update launch for models with a row every tuple touches
