@@ -349,16 +349,25 @@ __global__ void __launch_bounds__(256, 2) score_count_kernel(EvalDev ev, const T
             preb = tid < NI ? ev.col_b[item0 + tid] : 0.0;
             return;
         }
+        preb = (tid < NI && item0 + tid < I) ? ev.col_b[item0 + tid] : 0.0;
+        if (K1 + K2 == 0) {   // no vectors at all (MostPopular): nothing to clamp into
+#pragma unroll
+            for (int p = 0; p < PER; p++) pre[p] = (T)0;
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < PER; p++) {
             const int idx = tid + 256 * p, it = idx / KQ, k = idx % KQ;
             const int64_t j = (int64_t)item0 + it;
-            // one predicated load per element: the address is selected, not branched on
-            const T* src = k < K1 ? seg0 + j * K1 + k : seg1 + j * K2 + (k - K1);
+            // one unconditional load per element from an address clamped into the tables, the value selected afterwards
+            // (a load under a branch would be waited for before the next one is issued)
             const bool ok = j < I && k < K1 + K2;
-            pre[p] = ok ? *src : (T)0;
+            const int64_t jc = j < I ? j : (int64_t)I - 1;
+            const int kk = k < K1 + K2 ? k : 0;
+            const T* src = kk < K1 ? seg0 + jc * K1 + kk : seg1 + jc * K2 + (kk - K1);
+            const T v = *src;
+            pre[p] = ok ? v : (T)0;
         }
-        preb = (tid < NI && item0 + tid < I) ? ev.col_b[item0 + tid] : 0.0;
     };
 
     T pre[PER]; double preb; int preid;
