@@ -16,13 +16,19 @@ U, I, CLICKS, K = 1_000_000, 200_000, 100_000_000, 64
 
 
 @pytest.fixture(scope="module")
-def big():
+def corpus():
     import torch
-    import recommendation_amd as ra
-    from recommendation_amd.capi import F32
     from bench import make_synthetic
     seq_off, seq_item, test, val, _ = make_synthetic(U, I, CLICKS, 12345, torch.device("cuda:0"))
     torch.cuda.empty_cache()
+    return seq_off, seq_item, test, val
+
+
+@pytest.fixture(scope="module")
+def big(corpus):
+    import recommendation_amd as ra
+    from recommendation_amd.capi import F32
+    seq_off, seq_item, test, val = corpus
     eng = ra.Engine("BPRMF", I, seq_off, seq_item, test, val, K=K, lam=0.01, bias_reg=0.01, precision=F32)
     eng.init_params(seed=2024)
     yield eng, seq_off, seq_item, test, val
@@ -80,3 +86,33 @@ def test_full_shape_epoch_with_zero_learning_rate_changes_nothing(big):
     eng.sync()
     assert eng.tuples_drawn - before == eng.steps_per_epoch
     assert np.array_equal(eng.download(), W0)           # every scatter of the epoch added (or stored) a zero delta
+
+
+@pytest.mark.parametrize("model", ["FPMC", "TransRec", "HRM_avg", "Fossil"])
+def test_full_shape_other_models_replay_and_counts(corpus, model):
+    """The first-order and history models at the same size: replay of sampled tuples against updateFactors,
+    per-user counts of sampled users against model::AUC."""
+    import recommendation_amd as ra
+    from oracle import oracle_py as orc
+    from recommendation_amd.capi import F32, SEQUENTIAL
+    seq_off, seq_item, test, val = corpus
+    kw = dict(K=K, L=3, lam=0.01, bias_reg=0.01, relation_reg=0.01, alpha=0.5)
+    eng = ra.Engine(model, I, seq_off, seq_item, test, val, precision=F32, **kw)
+    eng.init_params(seed=7)
+    W0 = eng.download()
+    T = eng.sample_tuples(512, seed=3, epoch=1)
+    sample = np.linspace(0, U - 1, 512).astype(np.int64)
+    t_s = np.full(U, -1, np.int32); t_s[sample] = test[sample]
+    o = orc.Oracle(model, U, I, K, seq_off, seq_item, t_s, val, **{k: v for k, v in kw.items() if k != "K"})
+    ref = o.replay(W0, T, 0.05)
+    eng.sgd_replay(0.05, T, SEQUENTIAL)
+    W1 = eng.download()
+    touched = ref != W0
+    assert touched.sum() > 512 * K
+    err = np.abs(W1[touched] - ref[touched]) / np.maximum(np.abs(ref[touched]), 1e-1)
+    assert err.max() < 1e-5, (model, err.max())
+    assert np.array_equal(W1[~touched], W0[~touched])
+    _, counts, _ = eng.eval()
+    _, cref = o.eval(W1, nthreads=min(16, os.cpu_count() or 1))
+    assert np.array_equal(counts[sample], cref[sample]), model
+    eng.close()
