@@ -144,6 +144,7 @@ def main():
     ap.add_argument("--policy", type=int, default=-1, help="update_policy: 0 exact atomics, 1 hybrid, 2 plain stores; -1 = engine default")
     ap.add_argument("--chunk", type=int, default=1 << 27)
     ap.add_argument("--overlap", type=int, default=0)
+    ap.add_argument("--share-negative", type=int, default=0, help="share_negative of the group models (1, 2); 0 = engine default")
     ap.add_argument("--user-batch", type=int, default=0, help="user_batch of the history models (1, 2, 4, 8); 0 = engine default")
     ap.add_argument("--eval-users", type=int, default=0, help="evaluate only the first n users of each shard (0 = all)")
     ap.add_argument("--cpu-eval-users", type=int, default=16384, help="users of the CPU evaluation baseline (0 = skip)")
@@ -225,6 +226,11 @@ def main():
     eng.set_option("overlap", args.overlap)
     if args.user_batch > 0:
         eng.set_option("user_batch", args.user_batch)
+    if args.share_negative > 0:
+        eng.set_option("share_negative", args.share_negative)
+    # the engine's default: pairs of steps share their negative when an epoch is >= 4M steps (not TransRec, not the history models)
+    neg_share = args.share_negative if args.share_negative > 0 else \
+        (2 if eng.steps_per_epoch >= (1 << 22) and args.model in ("BPRMF", "MC", "FPMC", "PRME", "HRM_avg", "HRM_max") else 1)
     eng.set_option("profile", 1)
     steps_per_epoch = eng.steps_per_epoch
     my_steps = steps_per_epoch // world
@@ -300,8 +306,10 @@ def main():
 
     # what actually bounds the hybrid scatter: float atomics execute at the memory side at about 1.3 TB/s chip-wide
     atomic_rows = {"BPRMF": 2, "MC": 3, "HRM_avg": 3, "HRM_max": 3, "TransRec": 3, "TransRec_L1": 3, "FPMC": 5, "PRME": 5}.get(args.model)
+    neg_rows = {"BPRMF": 1, "MC": 1, "HRM_avg": 1, "HRM_max": 1, "FPMC": 2, "PRME": 2}.get(args.model, 0)
     if atomic_rows and policy == 1 and avg_ms > 0:
-        ab = atomic_rows * K * esz
+        # a negative shared by two steps is scattered once for both
+        ab = int((atomic_rows - (neg_rows / 2 if neg_share == 2 else 0)) * K * esz)
         rate = ab * tuples_per_launch / (avg_ms * 1e-3) / 1e9
         roofline["atomic"] = {"bytes_per_triple": ab, "achieved": round(rate, 1), "peak": 1300.0, "unit": "GB/s",
                               "frac": round(rate / 1300.0, 4)}
@@ -321,7 +329,7 @@ def main():
            "data": "synthetic",
            "config": {"workload": f"{args.model} K={K} oneiteration (BPR-SGD epoch) on synthetic {U} users x {I} items x "
                                   f"{n_clicks} interactions", "triples_per_step": my_steps * world,
-                      "update": ["float atomics on every row", "float atomics on item rows (plain stores for user rows, biases and items holding >= 1/1024 of the positives)", "plain stores"][policy] + (", chunks drawn by event and grouped by positive item, one atomic row per run" if grouped else ""), "parallelism": f"user-sharded x{world}"},
+                      "update": ["float atomics on every row", "float atomics on item rows (plain stores for user rows, biases and items holding >= 1/1024 of the positives)", "plain stores"][policy] + (", chunks drawn by event and grouped by positive item, one atomic row per run" if grouped else "") + ("; pairs of steps share their negative, scattered once for both" if neg_share == 2 and policy != 2 else ""), "parallelism": f"user-sharded x{world}"},
            "roofline": roofline}
 
     # ---------------- evaluation: users/s over the full catalog

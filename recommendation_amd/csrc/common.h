@@ -80,9 +80,10 @@ int launch_apply_global(const DevModel& m, int precision, double lr, int64_t n_t
 int launch_sgd_history(const DevModel& m, int precision, const int4* tuples, int64_t n, double lr, int atomic, int64_t max_in_flight,
                        int batch, hipStream_t st);
 int launch_apply_global_history(const DevModel& m, int precision, double lr, double cap, hipStream_t st);
-// user_batch > 1: every aligned group of user_batch consecutive steps shares its owner (user) draw
+// user_batch > 1: every aligned group of user_batch consecutive steps shares its owner (user) draw;
+// neg_share > 1: every aligned group of neg_share consecutive steps shares its stream of negative candidates
 int launch_sampler(const DevModel& m, int4* tuples, int64_t n, int64_t first_step, uint64_t seed, uint64_t epoch,
-                   hipStream_t st, int user_batch = 1);
+                   hipStream_t st, int user_batch = 1, int neg_share = 1);
 int launch_convert_in(const double* src, void* dst, int64_t n, int precision, hipStream_t st);
 int launch_convert_out(const void* src, double* dst, int64_t n, int precision, hipStream_t st);
 int launch_param_init(const DevModel& m, int precision, uint64_t seed, hipStream_t st);

@@ -26,11 +26,15 @@ struct Rng {
 
 template <int MODEL>
 __global__ void __launch_bounds__(256) sampler_kernel(DevModel m, int4* __restrict__ out, int64_t n, int64_t first_step,
-                                                      uint64_t seed, uint64_t epoch, int user_batch)
+                                                      uint64_t seed, uint64_t epoch, int user_batch, int neg_share)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Rng rng(seed, epoch, (uint64_t)(first_step + i));
+    // neg_share > 1: the steps of an aligned group of neg_share draw their negative candidates from one stream, each
+    // accepting the first candidate its own tuple allows - nearly always the same item for the whole group (whose
+    // rows the update kernel then scatters once), while every tuple's negative stays uniform over its own allowed set
+#define NEG_STREAM if (neg_share > 1) rng = Rng(seed ^ 0x8CB92BA72F3D8DD7ull, epoch, (uint64_t)(first_step + i) / (uint64_t)neg_share)
     uint32_t r_owner = rng.next();
     // user_batch > 1: steps g*user_batch .. (g+1)*user_batch-1 share one owner draw, everything else stays per step
     if (user_batch > 1) { Rng ro(seed ^ 0xD1B54A32D192ED03ull, epoch, (uint64_t)(first_step + i) / (uint64_t)user_batch); r_owner = ro.next(); }
@@ -48,7 +52,7 @@ __global__ void __launch_bounds__(256) sampler_kernel(DevModel m, int4* __restri
             const int64_t s0 = m.sset_off[e];
             return sorted_contains(m.sset_item + s0, (int)(m.sset_off[e + 1] - s0), item);
         };
-        int neg = 0;
+        NEG_STREAM; int neg = 0;
         for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (!successor(neg)) break; }
         t = make_int4(e, pos, neg, 0);
     } else {
@@ -64,7 +68,7 @@ __global__ void __launch_bounds__(256) sampler_kernel(DevModel m, int4* __restri
         if constexpr (MODEL == REC_BPRMF) {
             // BPRMF.cpp:74-83, 135-143
             const int pos = seq[bounded(rng.next(), (uint32_t)nu)];
-            int neg = 0;
+            NEG_STREAM; int neg = 0;
             for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (!clicked(neg)) break; }
             t = make_int4(e, pos, neg, 0);
         } else if constexpr (MODEL == REC_FPMC || MODEL == REC_PRME || MODEL == REC_FOSSIL_SIMPLE || MODEL == REC_HRM_AVG ||
@@ -72,7 +76,7 @@ __global__ void __launch_bounds__(256) sampler_kernel(DevModel m, int4* __restri
             // FPMC.cpp:140-151, PRME.cpp:120-132, FossilSimple.cpp:253-264, HRM_avg.cpp:153-159 + 171-174
             const int p = (int)bounded(rng.next(), (uint32_t)(nu - 1));
             const int prev = seq[p], pos = seq[p + 1];
-            int neg = 0;
+            NEG_STREAM; int neg = 0;
             for (int tr = 0; tr < MAX_TRIES; tr++) {
                 neg = (int)bounded(rng.next(), (uint32_t)m.I);
                 if (neg != pos && !(MODEL == REC_FOSSIL_SIMPLE && neg == prev)) break;
@@ -81,14 +85,14 @@ __global__ void __launch_bounds__(256) sampler_kernel(DevModel m, int4* __restri
         } else if constexpr (MODEL == REC_TRANSREC || MODEL == REC_TRANSREC_L1) {
             // TransRec.cpp:188-199
             const int p = (int)bounded(rng.next(), (uint32_t)(nu - 1));
-            int neg = 0;
+            NEG_STREAM; int neg = 0;
             for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (!clicked(neg)) break; }
             t = make_int4(e, seq[p], seq[p + 1], neg);
         } else if constexpr (MODEL == REC_FOSSIL) {
             // Fossil.cpp:282-293: target position 1..nu-1, negative outside {pos} + the <= L previous items
             const int tp = 1 + (int)bounded(rng.next(), (uint32_t)(nu - 1));
             const int pos = seq[tp]; const int lo = tp - m.L > 0 ? tp - m.L : 0;
-            int neg = 0;
+            NEG_STREAM; int neg = 0;
             for (int tr = 0; tr < MAX_TRIES; tr++) {
                 neg = (int)bounded(rng.next(), (uint32_t)m.I);
                 bool bad = neg == pos;
@@ -102,7 +106,7 @@ __global__ void __launch_bounds__(256) sampler_kernel(DevModel m, int4* __restri
             const int pos = seq[tp];
             const int64_t ctx = so + 2 * (int64_t)e + (tp - 1);
             const int32_t* path = m.path_item + m.path_off[ctx]; const int np = (int)(m.path_off[ctx + 1] - m.path_off[ctx]);
-            int neg = 0;
+            NEG_STREAM; int neg = 0;
             for (int tr = 0; tr < MAX_TRIES; tr++) {
                 neg = (int)bounded(rng.next(), (uint32_t)m.I);
                 bool bad = neg == pos;
@@ -115,13 +119,15 @@ __global__ void __launch_bounds__(256) sampler_kernel(DevModel m, int4* __restri
     out[i] = t;
 }
 
+#undef NEG_STREAM
+
 int launch_sampler(const DevModel& m, int4* tuples, int64_t n, int64_t first_step, uint64_t seed, uint64_t epoch,
-                   hipStream_t st, int user_batch)
+                   hipStream_t st, int user_batch, int neg_share)
 {
     if (n <= 0) return 0;
     if (m.n_elig <= 0) { rec_set_error("no user (or source item) is eligible for sampling"); return -1; }
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-#define SAMPLER_CASE(M) case M: hipLaunchKernelGGL(sampler_kernel<M>, grid, block, 0, st, m, tuples, n, first_step, seed, epoch, user_batch); break;
+#define SAMPLER_CASE(M) case M: hipLaunchKernelGGL(sampler_kernel<M>, grid, block, 0, st, m, tuples, n, first_step, seed, epoch, user_batch, neg_share); break;
     switch (m.model) {
         SAMPLER_CASE(REC_BPRMF) SAMPLER_CASE(REC_MC) SAMPLER_CASE(REC_FPMC) SAMPLER_CASE(REC_PRME)
         SAMPLER_CASE(REC_HRM_AVG) SAMPLER_CASE(REC_HRM_MAX) SAMPLER_CASE(REC_TRANSREC) SAMPLER_CASE(REC_TRANSREC_L1)

@@ -38,6 +38,9 @@ __global__ void __launch_bounds__(256) sgd_hogwild_kernel(DevModel m, const int4
         for (int j = 0; j < EPL; j++) { const int k = g + LPT * j; if (k < m.K) rg[j] = ((const T*)m.tab[TR_r])[k]; }
     }
 
+    // folding the rows two neighbouring tuples share: not for TransRec, whose step is bound by its arithmetic (the
+    // projections), not by its atomics - there the extra compares cost more than the saved scatter
+    constexpr bool FOLD = B % 2 == 0 && !TR;
     auto load_idx = [&](int64_t batch, int4 (&tp)[B]) {
 #pragma unroll
         for (int b = 0; b < B; b++) {
@@ -114,11 +117,31 @@ __global__ void __launch_bounds__(256) sgd_hogwild_kernel(DevModel m, const int4
             const T deri = step<MODEL, T, LPT, EPL>(m, lr, g, v[b], b0, b1, rg, racc, at[b]);
             if ((g >> 1) == b) mine = deri;
         }
+        // Neighbouring tuples that name the same item in the same role (the sampler's shared negatives) scatter
+        // that row once, with the sum of their two deltas: half the atomics for it, the same sum.
+        bool folded[B][R];
+#pragma unroll
+        for (int b = 0; b < B; b++)
+#pragma unroll
+            for (int r = 0; r < R; r++) folded[b][r] = false;
+        if constexpr (FOLD) {
+#pragma unroll
+            for (int b = 0; b < B; b += 2)
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int it0 = row_item<MODEL>(tp[b], r), it1 = row_item<MODEL>(tp[b + 1], r);
+                    const bool same = tp[b].x >= 0 && tp[b + 1].x >= 0 && it0 >= 0 && it0 == it1 && at[b][r] && at[b + 1][r];
+                    folded[b + 1][r] = same;
+#pragma unroll
+                    for (int j = 0; j < EPL; j++) v[b][r][j] += same ? v[b + 1][r][j] : (T)0;
+                }
+        }
 #pragma unroll
         for (int b = 0; b < B; b++) {
             if (tp[b].x < 0) continue;
 #pragma unroll
             for (int r = 0; r < R; r++) {
+                if (folded[b][r]) continue;
                 int width; T* row = row_ptr<MODEL, T>(m, tp[b], r, width);
 #pragma unroll
                 for (int j = 0; j < EPL; j++) { const int k = g + LPT * j; if (k < width) scatter(row + k, v[b][r][j], old[b][r][j], at[b][r]); }
@@ -127,10 +150,18 @@ __global__ void __launch_bounds__(256) sgd_hogwild_kernel(DevModel m, const int4
         if constexpr (NB == 2) {
             // BPRMF.cpp:92-93: +deri on the positive, -deri on the negative; TransRec.cpp:225-226: the opposite signs
             T* p = my_bias_ptr(tp);
-            if (p) {
-                const T sgn = ((g & 1) == 0) == (MODEL == REC_BPRMF) ? (T)1 : (T)-1;
-                scatter(p, lr * (sgn * mine - (T)m.bias_reg * bs), bs, ((atomic >> 8) & 1) && !bias_hot);
-            }
+            const T sgn = ((g & 1) == 0) == (MODEL == REC_BPRMF) ? (T)1 : (T)-1;
+            T delta = p ? lr * (sgn * mine - (T)m.bias_reg * bs) : (T)0;
+            // the same bias named by the neighbouring tuple in the same role (two lanes further on) is written once,
+            // with both deltas: as plain stores the two would otherwise lose one of them
+            const T* base = (const T*)m.tab[MODEL == REC_BPRMF ? BPRMF_BETA : TR_BETA];
+            const int mine_idx = p ? (int)(p - base) : -1;
+            const int next_idx = __shfl_down(mine_idx, 2, LPT), prev_idx = __shfl_up(mine_idx, 2, LPT);
+            const T next_delta = __shfl_down(delta, 2, LPT);
+            const bool first_of_pair = ((g >> 1) & 1) == 0;
+            if (FOLD && p && first_of_pair && g + 2 < 2 * B && next_idx == mine_idx) delta += next_delta;
+            const bool folded_bias = FOLD && p && !first_of_pair && prev_idx == mine_idx;
+            if (p && !folded_bias) scatter(p, delta, bs, ((atomic >> 8) & 1) && !bias_hot);
         }
         bs = bn; bias_hot = bias_hot_n; hf = hfn;
 #pragma unroll

@@ -74,6 +74,7 @@ def test_full_shape_sampler_support(big):
     for u, p, n, _ in T[:20000].tolist():
         s = seq_item[seq_off[u]:seq_off[u + 1]]
         assert (s == p).any() and not (s == n).any()     # BPRMF.cpp:74-83, 135-143
+    assert (T[0::2, 2] == T[1::2, 2]).mean() > 0.99       # the default at this size: pairs of steps share their negative
     # users uniform: the mean user id of 1M draws is within 5 sigma of (U - 1) / 2
     assert abs(T[:, 0].mean() - (U - 1) / 2) < 5 * U / np.sqrt(12 * len(T))
 
