@@ -182,9 +182,9 @@ int rec_table_info(const rec_engine* e, int t, void** dev_ptr, int64_t* rows, in
  *   "overlap"       1 = sample chunk c+1 on a second stream while chunk c is applied (default 0: measured slower)
  *   "event_phases"  event-major sampler only, before its first use: n > 0 orders the events by n item ranges of equal weight,
  *                   shuffled inside a range (experiment knob: how much item locality in time the SGD tolerates)
- *   "share_negative" BPRMF / MC / FPMC / PRME / HRM / TransRec: 2 = two consecutive steps of an epoch take their negative from one
+ *   "share_negative" BPRMF / MC / FPMC / PRME / HRM / TransRec: 2 (or 4) = that many consecutive steps of an epoch take their negative from one
  *                   stream of candidates (each accepting the first one its own tuple allows, so nearly always the same item)
- *                   and the update scatters that item's rows once for both (default 2 when an epoch is >= 4M steps, else 1)
+ *                   and the update scatters that item's rows once for all of them (default 2 when an epoch is >= 4M steps, TransRec and smaller epochs 1)
  *   "user_batch"    Fossil / FossilSimple / REBUS: 1, 2, 4 or 8 consecutive steps of an epoch share their user draw and one
  *                   wavefront walks that user's history once for all of them (default 2 when an epoch is >= 4M steps, else 1);
  *                   rec_sgd_replay in Hogwild mode then expects its tuples grouped the same way

@@ -848,7 +848,7 @@ extern "C" int rec_set_option(rec_engine* e, const char* name, int64_t value)
     else if (s == "run_hot") { if (value < 1) { rec_set_error("run_hot must be positive"); return -1; } e->run_policy.hot = (int)value; }
     else if (s == "run_hot_atomic") e->run_policy.hot_atomic = value != 0;
     else if (s == "event_phases") { if (value < 0 || e->dm.n_ev > 0) { rec_set_error("event_phases must be >= 0 and set before the first event-major epoch"); return -1; } e->event_phases = (int)value; }
-    else if (s == "share_negative") { if (value != 1 && value != 2) { rec_set_error("share_negative must be 1 or 2"); return -1; } e->neg_share = (int)value; }
+    else if (s == "share_negative") { if (value != 1 && value != 2 && value != 4) { rec_set_error("share_negative must be 1, 2 or 4"); return -1; } e->neg_share = (int)value; }
     else if (s == "user_batch") { if (value != 1 && value != 2 && value != 4 && value != 8) { rec_set_error("user_batch must be 1, 2, 4 or 8"); return -1; } e->user_batch = (int)value; }
     else if (s == "run_segment") { if (value < 0) { rec_set_error("run_segment must be >= 0"); return -1; } e->run_segment = value; }
     else if (s == "group_by_item") { if (value < 0 || value > 3) { rec_set_error("group_by_item must be 0..3"); return -1; } e->group = (int)value; }

@@ -117,23 +117,30 @@ __global__ void __launch_bounds__(256) sgd_hogwild_kernel(DevModel m, const int4
             const T deri = step<MODEL, T, LPT, EPL>(m, lr, g, v[b], b0, b1, rg, racc, at[b]);
             if ((g >> 1) == b) mine = deri;
         }
-        // Neighbouring tuples that name the same item in the same role (the sampler's shared negatives) scatter
-        // that row once, with the sum of their two deltas: half the atomics for it, the same sum.
+        // Tuples of a batch that name the same item in the same role (the sampler's shared negatives) scatter that
+        // row once, with the sum of their deltas: a fraction of the atomics for it, the same sum.
         bool folded[B][R];
 #pragma unroll
         for (int b = 0; b < B; b++)
 #pragma unroll
             for (int r = 0; r < R; r++) folded[b][r] = false;
         if constexpr (FOLD) {
+            // every tuple of the batch folds into the first one that names the same item in the same role
 #pragma unroll
-            for (int b = 0; b < B; b += 2)
+            for (int r = 0; r < R; r++)
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    const int it0 = row_item<MODEL>(tp[b], r), it1 = row_item<MODEL>(tp[b + 1], r);
-                    const bool same = tp[b].x >= 0 && tp[b + 1].x >= 0 && it0 >= 0 && it0 == it1 && at[b][r] && at[b + 1][r];
-                    folded[b + 1][r] = same;
+                for (int b = B - 1; b > 0; b--) {
+                    const int it1 = row_item<MODEL>(tp[b], r);
+                    const bool can = tp[b].x >= 0 && it1 >= 0 && at[b][r];
+                    int target = -1;
 #pragma unroll
-                    for (int j = 0; j < EPL; j++) v[b][r][j] += same ? v[b + 1][r][j] : (T)0;
+                    for (int c = b - 1; c >= 0; c--)
+                        if (can && tp[c].x >= 0 && at[c][r] && row_item<MODEL>(tp[c], r) == it1) target = c;
+                    folded[b][r] = target >= 0;
+#pragma unroll
+                    for (int c = 0; c < b; c++)
+#pragma unroll
+                        for (int j = 0; j < EPL; j++) v[c][r][j] += target == c ? v[b][r][j] : (T)0;
                 }
         }
 #pragma unroll
@@ -152,15 +159,21 @@ __global__ void __launch_bounds__(256) sgd_hogwild_kernel(DevModel m, const int4
             T* p = my_bias_ptr(tp);
             const T sgn = ((g & 1) == 0) == (MODEL == REC_BPRMF) ? (T)1 : (T)-1;
             T delta = p ? lr * (sgn * mine - (T)m.bias_reg * bs) : (T)0;
-            // the same bias named by the neighbouring tuple in the same role (two lanes further on) is written once,
-            // with both deltas: as plain stores the two would otherwise lose one of them
+            // a bias named by several tuples of the batch in the same role is written once, by the first of them, with
+            // all their deltas: as plain stores they would otherwise lose all but one
             const T* base = (const T*)m.tab[MODEL == REC_BPRMF ? BPRMF_BETA : TR_BETA];
             const int mine_idx = p ? (int)(p - base) : -1;
-            const int next_idx = __shfl_down(mine_idx, 2, LPT), prev_idx = __shfl_up(mine_idx, 2, LPT);
-            const T next_delta = __shfl_down(delta, 2, LPT);
-            const bool first_of_pair = ((g >> 1) & 1) == 0;
-            if (FOLD && p && first_of_pair && g + 2 < 2 * B && next_idx == mine_idx) delta += next_delta;
-            const bool folded_bias = FOLD && p && !first_of_pair && prev_idx == mine_idx;
+            const T own = delta;
+            bool folded_bias = false;
+            if constexpr (FOLD) {
+#pragma unroll
+                for (int d = 1; d < B; d++) {   // the same role of the tuple d places further on / back: 2d lanes away
+                    const int next_idx = __shfl_down(mine_idx, 2 * d, LPT), prev_idx = __shfl_up(mine_idx, 2 * d, LPT);
+                    const T next_delta = __shfl_down(own, 2 * d, LPT);
+                    if (p && g + 2 * d < 2 * B && next_idx == mine_idx) delta += next_delta;
+                    if (p && g - 2 * d >= 0 && prev_idx == mine_idx) folded_bias = true;
+                }
+            }
             if (p && !folded_bias) scatter(p, delta, bs, ((atomic >> 8) & 1) && !bias_hot);
         }
         bs = bn; bias_hot = bias_hot_n; hf = hfn;
