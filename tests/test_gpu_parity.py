@@ -491,12 +491,13 @@ def test_user_batched_epochs_train(model, G):
     e.close()
 
 
+@pytest.mark.parametrize("share", [2, 4])
 @pytest.mark.parametrize("policy", ["atomic", "hybrid"])
 @pytest.mark.parametrize("model", ["BPRMF", "MC", "FPMC", "PRME", "HRM_avg", "HRM_max"])
-def test_pairs_sharing_a_negative_are_scattered_once_with_the_sum(model, policy):
-    """Option share_negative: two consecutive steps take the first candidate of one stream that their own tuple
-    allows (nearly always the same item), and the update kernel folds the rows (and biases) the two tuples share
-    into one scatter: the result is the sum of the two single-tuple updateFactors deltas."""
+def test_steps_sharing_a_negative_are_scattered_once_with_the_sum(model, policy, share):
+    """Option share_negative: 2 or 4 consecutive steps take the first candidate of one stream that their own
+    tuple allows (nearly always the same item), and the update kernel folds the rows (and biases) the tuples of a
+    batch share into one scatter: the result is the sum of the single-tuple updateFactors deltas."""
     g, model, co, ci, labels = fixture_case(model, "toy")
     o = make_oracle(g, model, co, ci, labels)
     lr = float(g["lr"]); W0 = g["W0"]
@@ -506,34 +507,36 @@ def test_pairs_sharing_a_negative_are_scattered_once_with_the_sum(model, policy)
     else:   # user rows and biases stored plainly, item rows atomic, no item exempt
         e.set_option("update_policy", 1)
         e.set_option("hot_count", 0)
-    T1 = e.sample_tuples(4096, seed=5, epoch=2)
-    e.set_option("share_negative", 2)
-    T = e.sample_tuples(4096, seed=5, epoch=2)
-    assert np.array_equal(T[:, :-1] if model in ("FPMC", "PRME", "HRM_avg", "HRM_max") else T[:, :2], T1[:, :-1] if model in ("FPMC", "PRME", "HRM_avg", "HRM_max") else T1[:, :2])  # only the negatives changed
-    neg = T[:, 3] if model in ("FPMC", "PRME", "HRM_avg", "HRM_max") else T[:, 2]
-    assert (neg[0::2] == neg[1::2]).mean() > 0.6           # pairs share their negative (always, but for candidates one of the two has clicked: many on this tiny catalog) ...
-    assert len(np.unique(neg[0::2])) > 0.2 * len(np.unique(neg))   # ... and different pairs draw different ones
+    four = model in ("FPMC", "PRME", "HRM_avg", "HRM_max")
+    nf = 3 if four else 2            # item fields of a tuple
+    T1 = e.sample_tuples(8192, seed=5, epoch=2)
+    e.set_option("share_negative", share)
+    T = e.sample_tuples(8192, seed=5, epoch=2)
+    assert np.array_equal(T[:, :nf], T1[:, :nf])             # only the negatives changed
+    neg = T[:, nf]
+    # groups share their negative (always, but for candidates one of them has clicked: many on this tiny catalog) ...
+    assert (neg.reshape(-1, share) == neg[::share, None]).all(axis=1).mean() > (0.6 if share == 2 else 0.3)
+    assert len(np.unique(neg[::share])) > 0.2 * len(np.unique(neg))   # ... and different groups draw different ones
     done = 0
-    for k in range(0, len(T), 2):
-        pair = T[k:k + 2]
-        if neg[k] != neg[k + 1] or pair[0, 0] == pair[1, 0]:
-            continue
-        nf = 3 if model in ("FPMC", "PRME", "HRM_avg", "HRM_max") else 2
-        if any(len(set(t[1:1 + nf].tolist())) < nf for t in pair):
+    for k in range(0, len(T), share):
+        grp = T[k:k + share]
+        if len(set(grp[:, nf].tolist())) != 1 or len(set(grp[:, 0].tolist())) != share:
+            continue   # wanted: one negative, different owners (their rows are plain stores in the hybrid policy)
+        if any(len(set(t[1:1 + nf].tolist())) < nf for t in grp):
             continue   # a tuple that names one item twice: the reference's in-place second update sees the first
-        if policy == "hybrid" and model == "BPRMF" and (pair[0, 1] == pair[1, 2] or pair[1, 1] == pair[0, 2]):
-            continue   # one tuple's positive is the other's negative: two plain bias stores to one address
+        if policy == "hybrid" and model == "BPRMF" and set(grp[:, 1].tolist()) & set(grp[:, 2].tolist()):
+            continue   # one tuple's positive is another's negative: plain bias stores of different roles to one address
         ref = W0.copy()
-        for t in pair:
+        for t in grp:
             ref += o.replay(W0, t[None, :], lr) - W0
         e.upload(W0)
-        e.sgd_replay(lr, pair, HOGWILD)
+        e.sgd_replay(lr, grp, HOGWILD)
         err = rel_err(e.download(), ref, floor=1e-1)
-        assert err < 1e-9, (model, policy, pair, err)
+        assert err < 1e-9, (model, policy, grp, err)
         done += 1
         if done == 40:
             break
-    assert done >= 20
+    assert done >= 10
     e.close()
 
 
