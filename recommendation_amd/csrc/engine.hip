@@ -526,10 +526,10 @@ static int launch_update(rec_engine* e, const int4* tuples, int64_t n, double lr
     const bool history = model == REC_FOSSIL || model == REC_FOSSIL_SIMPLE || model == REC_REBUS;
     const bool global_row = model == REC_TRANSREC || model == REC_TRANSREC_L1 || model == REC_FOSSIL || model == REC_FOSSIL_SIMPLE;
     int64_t window = global_row ? e->global_window : n;
-    if ((user_batch > 1 || e->neg_share > 1) && window > 8) window &= ~(int64_t)7;   // launches start on a group boundary
     // Small catalogs: the history kernel bounds the tuples in flight inside one launch (one tuple per wavefront, so
     // fewer wavefronts); the group kernels are launched in windows of that many tuples.
     if (!history && e->stale_window > 0 && e->stale_window < window) window = e->stale_window;
+    if (window < n && (user_batch > 1 || e->neg_share > 1) && window > 8) window &= ~(int64_t)7;   // launches start on a group boundary
     for (int64_t o = 0; o < n; o += window) {
         const int64_t len = std::min(window, n - o);
         int rc = history ? launch_sgd_history(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic, e->stale_window, user_batch, e->st)
