@@ -184,7 +184,8 @@ int rec_table_info(const rec_engine* e, int t, void** dev_ptr, int64_t* rows, in
  *                   shuffled inside a range (experiment knob: how much item locality in time the SGD tolerates)
  *   "share_negative" BPRMF / MC / FPMC / PRME / HRM / TransRec: 2 (or 4) = that many consecutive steps of an epoch take their negative from one
  *                   stream of candidates (each accepting the first one its own tuple allows, so nearly always the same item)
- *                   and the update scatters that item's rows once for all of them (default 2 when an epoch is >= 4M steps, TransRec and smaller epochs 1)
+ *                   and the update scatters that item's rows once for all of them (default 2 when an epoch is >= 4M steps, TransRec and smaller
+ *                   epochs 1).  Measured: 1.25x the throughput, test AUC within 0.001, HIT@50 1-3 % lower (relative); 1 = independent draws
  *   "user_batch"    Fossil / FossilSimple / REBUS: 1, 2, 4 or 8 consecutive steps of an epoch share their user draw and one
  *                   wavefront walks that user's history once for all of them (default 2 when an epoch is >= 4M steps, else 1);
  *                   rec_sgd_replay in Hogwild mode then expects its tuples grouped the same way
