@@ -603,14 +603,13 @@ extern "C" int rec_sgd_replay(rec_engine* e, double lr, const int32_t* tuples, i
         if (int rc = launch_sgd_sequential(e->dm, e->desc.precision, e->tuples, n, lr, e->st)) return rc;
         ENG_HIP(hipStreamSynchronize(e->st));
     } else if (mode == REC_REPLAY_HOGWILD) {
-        const int ub = history_model(e->desc.model) ? e->user_batch : 1;
+        // the batched history kernel takes every aligned group of user_batch tuples as one user's: tuples that do not
+        // come that way are walked one by one
+        int ub = history_model(e->desc.model) ? e->user_batch : 1;
         int64_t chunk = e->chunk;
-        if (ub > 1) {
-            // the batched kernel takes every aligned group of user_batch tuples as one user's
-            for (int64_t i = 0; i < n; i++)
-                if (tuples[4 * i] != tuples[4 * (i - i % ub)]) { rec_set_error("tuple " + std::to_string(i) + ": user_batch is set but the tuples are not grouped by user"); return -1; }
-            chunk = std::max<int64_t>(8, chunk & ~(int64_t)7);
-        }
+        for (int64_t i = 0; i < n && ub > 1; i++)
+            if (tuples[4 * i] != tuples[4 * (i - i % ub)]) ub = 1;
+        if (ub > 1 || e->neg_share > 1) chunk = std::max<int64_t>(8, chunk & ~(int64_t)7);
         for (int64_t o = 0; o < n; o += chunk) {
             const int64_t len = std::min(chunk, n - o);
             if (int rc = ev_begin(e, 0, &a, &b)) return rc;

@@ -437,10 +437,17 @@ def test_user_batched_history_kernel_sums_the_single_tuple_steps(model, G):
             n_clean += 1
             assert err < 1e-9, (model, G, k, err)
     assert n_clean >= 5
-    # tuples that are not grouped by user are refused
-    bad = T[:2 * G].copy(); bad[1] = T[T[:, 0] != bad[0, 0]][0]
-    with pytest.raises(RuntimeError, match="not grouped by user"):
-        e.sgd_replay(lr, bad, HOGWILD)
+    # tuples that are not grouped by user are walked one by one: two tuples of users without a common item
+    a = T[0]; hist_a = set(seq_item[seq_off[a[0]]:seq_off[a[0] + 1]].tolist()) | {int(x) for x in a[1:]}
+    for b in T:
+        hist_b = set(seq_item[seq_off[b[0]]:seq_off[b[0] + 1]].tolist()) | {int(x) for x in b[1:]}
+        if b[0] != a[0] and not (hist_a & hist_b) and not aliased(a) and not aliased(b):
+            mixed = np.stack([a, b])
+            ref = W0 + (o.replay(W0, a[None, :], lr) - W0) + (o.replay(W0, b[None, :], lr) - W0)
+            e.upload(W0)
+            e.sgd_replay(lr, mixed, HOGWILD)
+            assert rel_err(e.download(), ref, floor=1e-1) < 1e-9
+            break
     e.close()
 
 
