@@ -187,7 +187,9 @@ int rec_table_info(const rec_engine* e, int t, void** dev_ptr, int64_t* rows, in
  *                   and the update scatters that item's rows once for all of them (default 2 when an epoch is >= 4M steps, TransRec and smaller
  *                   epochs 1).  Measured: 1.25x the throughput, test AUC within 0.001, HIT@50 1-3 % lower (relative); 1 = independent draws
  *   "user_batch"    Fossil / FossilSimple / REBUS: 1, 2, 4 or 8 consecutive steps of an epoch share their user draw and one
- *                   wavefront walks that user's history once for all of them (default 2 when an epoch is >= 4M steps, else 1);
+ *                   wavefront walks that user's history once for all of them (default 2 when an epoch is >= 4M steps and the mean
+ *                   training sequence has >= 16 clicks, else 1: with very short histories the tuples of a group mostly coincide
+ *                   and the summed step can diverge);
  *                   (rec_sgd_replay in Hogwild mode uses it when its tuples come grouped the same way)
  *   "stale_window"  tuples per update launch for small catalogs (0 = no limit)
  *   "global_window" tuples per update launch for models with a row every tuple touches

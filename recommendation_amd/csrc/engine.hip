@@ -301,11 +301,14 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     if (d->model == REC_TRANSREC || d->model == REC_TRANSREC_L1) e->global_window = 1 << 22;
     // scatter policy: exact sums for small problems, the hybrid for large ones (see rec_set_option)
     rec_set_option(e, "update_policy", e->steps_per_epoch >= (1 << 22) ? 1 : 0);
-    // The history models walk a user's history once for two tuples of that user.  Measured on a 200k-user corpus:
-    // 1.3x (REBUS) / 1.8x (Fossil, FossilSimple) the throughput; early-stopped test AUC equal within run-to-run noise
-    // (lr 0.01: 0.8125 vs 0.8124; lr 0.05, REBUS: 0.7794 vs 0.7789; Fossil at lr 0.05: equal at the best validation
-    // epoch, 0.003 lower after 15 epochs).  "user_batch" 1 restores one tuple per walk.
-    e->user_batch = (history_model(d->model) && e->steps_per_epoch >= (1 << 22)) ? 2 : 1;
+    // The history models walk a user's history once for two tuples of that user.  Measured on a 200k-user corpus with
+    // ~100 clicks per user: 1.3x (REBUS) / 1.8x (Fossil, FossilSimple) the throughput; early-stopped test AUC equal within
+    // run-to-run noise (lr 0.01: 0.8125 vs 0.8124; lr 0.05, REBUS: 0.7794 vs 0.7789).  Both tuples step from the same
+    // parameters, which on users with a handful of clicks (where the two tuples mostly coincide) doubles the step: on
+    // the bundled ML-5 corpus (<= 3 training clicks per user) REBUS at lr 0.05 then diverges in about 1 run of 10.  So
+    // pairs are only the default where histories are long; "user_batch" sets it either way.
+    const double mean_history = U > 0 ? (double)E / (double)U : 0.0;
+    e->user_batch = (history_model(d->model) && e->steps_per_epoch >= (1 << 22) && mean_history >= 16.0) ? 2 : 1;
     // The other models draw the negatives of two consecutive steps from one candidate stream (sampler.hip), and the update
     // kernel scatters the shared negative's rows once for both.  Measured on the same corpus: 1.2-1.3x the throughput;
     // early-stopped test AUC after 15-20 epochs lower by 0.0002 (FPMC, TransRec) to 0.0018 (HRM_avg), BPRMF 0.0008.

@@ -250,8 +250,10 @@ static int dispatch_shape(const DevModel& m, const int4* tuples, int64_t n, doub
     constexpr int B1 = R <= 4 ? 4 : 2;  // tuples in flight per group, by register budget
     if (Kmax <= 16) go(sgd_hogwild_kernel<MODEL, T, 16, 1, B1>, 16, B1);
     else if (Kmax <= 32) go(sgd_hogwild_kernel<MODEL, T, 32, 1, B1>, 32, B1);
-    else if (Kmax <= 64) go(sgd_hogwild_kernel<MODEL, T, 64, 1, B1>, 64, B1);
-    else if (Kmax <= 128) go(sgd_hogwild_kernel<MODEL, T, 64, 2, 2>, 64, 2);
+    // 32 lanes per tuple from K = 33 on: a wave-instruction then serves two tuples with two 128-byte row segments
+    // (the shape float atomics still run at full rate on) and the per-tuple arithmetic costs half the issue slots
+    else if (Kmax <= 64) go(sgd_hogwild_kernel<MODEL, T, 32, 2, B1>, 32, B1);
+    else if (Kmax <= 128) go(sgd_hogwild_kernel<MODEL, T, 32, 4, 2>, 32, 2);
     else if (Kmax <= 256) go(sgd_hogwild_kernel<MODEL, T, 64, 4, 1>, 64, 1);
     else { rec_set_error("K > 256 is not supported"); return -1; }
     HIP_TRY(hipGetLastError());

