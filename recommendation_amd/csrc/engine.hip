@@ -537,7 +537,7 @@ static int launch_update(rec_engine* e, const int4* tuples, int64_t n, double lr
         const int64_t len = std::min(window, n - o);
         int rc = history ? launch_sgd_history(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic, e->stale_window, user_batch, e->st)
                  : ((grouped || e->group == 1) && sgd_runs_supported(model)) ? launch_sgd_runs(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic, e->run_segment, e->run_policy, e->st)
-                         : launch_sgd_hogwild(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic, e->st);
+                         : launch_sgd_hogwild(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic | ((e->neg_share >= 4 ? 2 : e->neg_share == 2 ? 1 : 0) << 16), e->st);
         if (rc) return rc;
         if (global_row) {
             if ((rc = launch_apply_global(e->dm, e->desc.precision, lr, len, (double)e->global_cap, e->st))) return rc;

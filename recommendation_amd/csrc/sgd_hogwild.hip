@@ -41,6 +41,7 @@ __global__ void __launch_bounds__(256) sgd_hogwild_kernel(DevModel m, const int4
     // folding the rows two neighbouring tuples share: not for TransRec, whose step is bound by its arithmetic (the
     // projections), not by its atomics - there the extra compares cost more than the saved scatter
     constexpr bool FOLD = B % 2 == 0 && !TR;
+    const int fold_reach = (atomic >> 16) & 3;   // 0: no folding, 1: aligned pairs of tuples, 2: every tuple of a batch
     auto load_idx = [&](int64_t batch, int4 (&tp)[B]) {
 #pragma unroll
         for (int b = 0; b < B; b++) {
@@ -124,7 +125,20 @@ __global__ void __launch_bounds__(256) sgd_hogwild_kernel(DevModel m, const int4
         for (int b = 0; b < B; b++)
 #pragma unroll
             for (int r = 0; r < R; r++) folded[b][r] = false;
-        if constexpr (FOLD) {
+        if (FOLD && fold_reach == 1) {
+            // aligned pairs only (what the sampler's shared negatives produce by default): one compare per row
+#pragma unroll
+            for (int b = 0; b + 1 < B; b += 2)
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int it0 = row_item<MODEL>(tp[b], r), it1 = row_item<MODEL>(tp[b + 1], r);
+                    const bool same = tp[b].x >= 0 && tp[b + 1].x >= 0 && it0 >= 0 && it0 == it1 && at[b][r] && at[b + 1][r];
+                    folded[b + 1][r] = same;
+#pragma unroll
+                    for (int j = 0; j < EPL; j++) v[b][r][j] += same ? v[b + 1][r][j] : (T)0;
+                }
+        }
+        if (FOLD && fold_reach == 2) {
             // every tuple of the batch folds into the first one that names the same item in the same role
 #pragma unroll
             for (int r = 0; r < R; r++)
@@ -168,10 +182,12 @@ __global__ void __launch_bounds__(256) sgd_hogwild_kernel(DevModel m, const int4
             if constexpr (FOLD) {
 #pragma unroll
                 for (int d = 1; d < B; d++) {   // the same role of the tuple d places further on / back: 2d lanes away
+                    if (fold_reach == 0 || (fold_reach == 1 && d > 1)) break;
                     const int next_idx = __shfl_down(mine_idx, 2 * d, LPT), prev_idx = __shfl_up(mine_idx, 2 * d, LPT);
                     const T next_delta = __shfl_down(own, 2 * d, LPT);
-                    if (p && g + 2 * d < 2 * B && next_idx == mine_idx) delta += next_delta;
-                    if (p && g - 2 * d >= 0 && prev_idx == mine_idx) folded_bias = true;
+                    const bool pair_ok = fold_reach == 2 || (((g >> 1) & 1) == 0);   // pairs: the even tuple takes the odd one's delta
+                    if (p && pair_ok && g + 2 * d < 2 * B && next_idx == mine_idx) delta += next_delta;
+                    if (p && (fold_reach == 2 || ((g >> 1) & 1) == 1) && g - 2 * d >= 0 && prev_idx == mine_idx) folded_bias = true;
                 }
             }
             if (p && !folded_bias) scatter(p, delta, bs, ((atomic >> 8) & 1) && !bias_hot);
