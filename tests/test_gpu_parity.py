@@ -486,7 +486,7 @@ def test_user_batched_epochs_train(model, G):
     m0, _, _ = e.eval()
     n = e.steps_per_epoch + 3
     for ep in range(30):
-        e.sgd_epoch(0.05, n, seed=11, epoch=ep)
+        e.sgd_epoch(0.02, n, seed=11, epoch=ep)   # a small step: on histories this short the tuples of a group mostly coincide
     e.sync()
     assert e.tuples_drawn == 30 * n
     W = e.download()
