@@ -144,6 +144,7 @@ def main():
     ap.add_argument("--policy", type=int, default=-1, help="update_policy: 0 exact atomics, 1 hybrid, 2 plain stores; -1 = engine default")
     ap.add_argument("--chunk", type=int, default=1 << 27)
     ap.add_argument("--overlap", type=int, default=0)
+    ap.add_argument("--share-positive", type=int, default=0, help="share_positive of the group models (1, 2); 0 = engine default")
     ap.add_argument("--share-negative", type=int, default=0, help="share_negative of the group models (1, 2); 0 = engine default")
     ap.add_argument("--user-batch", type=int, default=0, help="user_batch of the history models (1, 2, 4, 8); 0 = engine default")
     ap.add_argument("--eval-users", type=int, default=0, help="evaluate only the first n users of each shard (0 = all)")
@@ -228,6 +229,9 @@ def main():
         eng.set_option("user_batch", args.user_batch)
     if args.share_negative > 0:
         eng.set_option("share_negative", args.share_negative)
+    if args.share_positive > 0:
+        eng.set_option("share_positive", args.share_positive)
+    pos_share = args.share_positive if args.share_positive > 0 else 1
     # the engine's default: pairs of steps share their negative when an epoch is >= 4M steps (not TransRec, not the history models)
     neg_share = args.share_negative if args.share_negative > 0 else \
         (2 if eng.steps_per_epoch >= (1 << 22) and args.model in ("BPRMF", "MC", "FPMC", "PRME", "HRM_avg", "HRM_max") else 1)
@@ -309,7 +313,8 @@ def main():
     neg_rows = {"BPRMF": 1, "MC": 1, "HRM_avg": 1, "HRM_max": 1, "FPMC": 2, "PRME": 2}.get(args.model, 0)
     if atomic_rows and policy == 1 and avg_ms > 0:
         # a negative shared by two steps is scattered once for both
-        ab = int((atomic_rows - (neg_rows / 2 if neg_share == 2 else 0)) * K * esz)
+        ab = int((atomic_rows - (neg_rows / 2 if (neg_share == 2 or pos_share == 2) else neg_rows * 3 / 4 if neg_share == 4 else 0)
+                  - (neg_rows / 2 if pos_share == 2 else 0)) * K * esz)   # a model has as many positive rows as negative ones
         rate = ab * tuples_per_launch / (avg_ms * 1e-3) / 1e9
         roofline["atomic"] = {"bytes_per_triple": ab, "achieved": round(rate, 1), "peak": 1300.0, "unit": "GB/s",
                               "frac": round(rate / 1300.0, 4)}
@@ -329,7 +334,7 @@ def main():
            "data": "synthetic",
            "config": {"workload": f"{args.model} K={K} oneiteration (BPR-SGD epoch) on synthetic {U} users x {I} items x "
                                   f"{n_clicks} interactions", "triples_per_step": my_steps * world,
-                      "update": ["float atomics on every row", "float atomics on item rows (plain stores for user rows, biases and items holding >= 1/1024 of the positives)", "plain stores"][policy] + (", chunks drawn by event and grouped by positive item, one atomic row per run" if grouped else "") + ("; pairs of steps share their negative, scattered once for both" if neg_share == 2 and policy != 2 else ""), "parallelism": f"user-sharded x{world}"},
+                      "update": ["float atomics on every row", "float atomics on item rows (plain stores for user rows, biases and items holding >= 1/1024 of the positives)", "plain stores"][policy] + (", chunks drawn by event and grouped by positive item, one atomic row per run" if grouped else "") + ("; pairs of steps share their positive and their negative, each scattered once for both" if pos_share == 2 and policy != 2 else "; pairs of steps share their negative, scattered once for both" if neg_share == 2 and policy != 2 else ""), "parallelism": f"user-sharded x{world}"},
            "roofline": roofline}
 
     # ---------------- evaluation: users/s over the full catalog

@@ -43,6 +43,11 @@ struct DevModel {
     const int4* ev;                     // [n_ev] sampling events ordered by positive item: (owner, aux, positive, -), see launch_event_sampler
     const float* ev_w;                  // [n_ev] 1 / (number of events of the owner)
     int64_t n_ev;
+    // pairs of steps that share their positive item: the events of item i are ev[ev_off[i], ev_off[i+1]); slot k of that
+    // range is taken with probability ev_alias_p[k], else slot ev_alias_i[k] (Walker's alias method over ev_w)
+    const int64_t* ev_off;              // [I+1]
+    const float* ev_alias_p;            // [n_ev]
+    const int32_t* ev_alias_i;          // [n_ev] slot inside the item's range
     const int32_t* train_count;         // [I] occurrences of each item in the training sequences (MostPopular)
     const uint8_t* hot;                 // [I+1] 1 = item whose rows are not scattered with atomics (see rec_set_option "hot_count")
 };
@@ -100,6 +105,10 @@ int launch_sgd_runs(const DevModel& m, int precision, const int4* tuples, int64_
 // Event-major sampling: every sampling event (an owner's position) independently yields Poisson(n_expected *
 // P(event)) tuples, written in event order, i.e. grouped by positive item.  *n_out_dev (device, int64) receives
 // the number of tuples drawn (its mean is n_expected); at most cap are written.  scratch: event_scratch_bytes().
+// Steps 2p and 2p+1 of the launch as a pair: the first is drawn as launch_sampler draws it, the second is another
+// event of the first one's positive item, drawn with the events' own weights (so that its (owner, position) has the
+// same distribution as the first one's), and both take their negative from one stream of candidates.
+int launch_pair_sampler(const DevModel& m, int4* tuples, int64_t n, int64_t first_step, uint64_t seed, uint64_t epoch, hipStream_t st);
 size_t event_scratch_bytes(int64_t n_ev);
 int launch_event_sampler(const DevModel& m, int4* tuples, int64_t cap, int64_t n_expected, int64_t first_step, uint64_t chunk_no,
                          uint64_t seed, uint64_t epoch, void* scratch, int64_t* n_out_dev, hipStream_t st);

@@ -48,6 +48,7 @@ struct rec_engine {
     RunPolicy run_policy = {128, 32, 0};
     int64_t run_segment = 0;  // batches per lane group in the run-combining kernel (0 = automatic)
     int event_phases = 0; // event-major sampler: > 0 = events ordered by that many item ranges of equal weight, shuffled inside a range
+    int pos_share = 1;   // 2: steps 2p, 2p+1 of an epoch also share their positive item (launch_pair_sampler)
     int neg_share = 1;   // consecutive steps of an epoch that share their stream of negative candidates (group models)
     int user_batch = 1;  // consecutive steps of an epoch that share their user draw (history models)
     int group = 0;       // 1: run-combining update kernel on the tuples as they come; 2: also sample by event, which yields chunks grouped by positive item
@@ -510,6 +511,32 @@ static int ensure_events(rec_engine* e)
     }
     if (int rc = upload(e, ev, &m.ev)) return rc;
     if (int rc = upload(e, ev_w, &m.ev_w)) return rc;
+    // per item: where its events are, and an alias table over their weights (Vose's construction)
+    {
+        std::vector<int64_t> ev_off(I + 1, 0);
+        for (int i = 0; i < I; i++) ev_off[i + 1] = start[i];   // start[i] is the end of item i's events
+        std::vector<float> ap(total, 1.0f); std::vector<int32_t> ai(total, 0);
+        std::vector<double> scaled; std::vector<int32_t> small, large;
+        for (int i = 0; i < I; i++) {
+            const int64_t a0 = ev_off[i], cnt = ev_off[i + 1] - a0;
+            if (cnt <= 0) continue;
+            double sum = 0;
+            for (int64_t k = 0; k < cnt; k++) sum += ev_w[a0 + k];
+            scaled.resize(cnt); small.clear(); large.clear();
+            for (int64_t k = 0; k < cnt; k++) { scaled[k] = ev_w[a0 + k] * (double)cnt / sum; (scaled[k] < 1.0 ? small : large).push_back((int32_t)k); ai[a0 + k] = (int32_t)k; }
+            while (!small.empty() && !large.empty()) {
+                const int32_t sidx = small.back(), lidx = large.back(); small.pop_back();
+                ap[a0 + sidx] = (float)scaled[sidx]; ai[a0 + sidx] = lidx;
+                scaled[lidx] -= 1.0 - scaled[sidx];
+                if (scaled[lidx] < 1.0) { large.pop_back(); small.push_back(lidx); }
+            }
+            for (int32_t k : small) ap[a0 + k] = 1.0f;
+            for (int32_t k : large) ap[a0 + k] = 1.0f;
+        }
+        if (int rc = upload(e, ev_off, &m.ev_off)) return rc;
+        if (int rc = upload(e, ap, &m.ev_alias_p)) return rc;
+        if (int rc = upload(e, ai, &m.ev_alias_i)) return rc;
+    }
     ENG_HIP(hipMalloc(&e->group_scratch, event_scratch_bytes(total)));
     e->owned.push_back(e->group_scratch);
     ENG_HIP(hipMalloc((void**)&e->n_drawn_dev, 64));
@@ -532,12 +559,12 @@ static int launch_update(rec_engine* e, const int4* tuples, int64_t n, double lr
     // Small catalogs: the history kernel bounds the tuples in flight inside one launch (one tuple per wavefront, so
     // fewer wavefronts); the group kernels are launched in windows of that many tuples.
     if (!history && e->stale_window > 0 && e->stale_window < window) window = e->stale_window;
-    if (window < n && (user_batch > 1 || e->neg_share > 1) && window > 8) window &= ~(int64_t)7;   // launches start on a group boundary
+    if (window < n && (user_batch > 1 || e->neg_share > 1 || e->pos_share > 1) && window > 8) window &= ~(int64_t)7;   // launches start on a group boundary
     for (int64_t o = 0; o < n; o += window) {
         const int64_t len = std::min(window, n - o);
         int rc = history ? launch_sgd_history(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic, e->stale_window, user_batch, e->st)
                  : ((grouped || e->group == 1) && sgd_runs_supported(model)) ? launch_sgd_runs(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic, e->run_segment, e->run_policy, e->st)
-                         : launch_sgd_hogwild(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic | ((e->neg_share >= 4 ? 2 : e->neg_share == 2 ? 1 : 0) << 16), e->st);
+                         : launch_sgd_hogwild(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic | ((e->neg_share >= 4 ? 2 : (e->neg_share == 2 || e->pos_share == 2) ? 1 : 0) << 16), e->st);
         if (rc) return rc;
         if (global_row) {
             if ((rc = launch_apply_global(e->dm, e->desc.precision, lr, len, (double)e->global_cap, e->st))) return rc;
@@ -612,7 +639,7 @@ extern "C" int rec_sgd_replay(rec_engine* e, double lr, const int32_t* tuples, i
         int64_t chunk = e->chunk;
         for (int64_t i = 0; i < n && ub > 1; i++)
             if (tuples[4 * i] != tuples[4 * (i - i % ub)]) ub = 1;
-        if (ub > 1 || e->neg_share > 1) chunk = std::max<int64_t>(8, chunk & ~(int64_t)7);
+        if (ub > 1 || e->neg_share > 1 || e->pos_share > 1) chunk = std::max<int64_t>(8, chunk & ~(int64_t)7);
         for (int64_t o = 0; o < n; o += chunk) {
             const int64_t len = std::min(chunk, n - o);
             if (int rc = ev_begin(e, 0, &a, &b)) return rc;
@@ -635,10 +662,11 @@ extern "C" int rec_sgd_epoch(rec_engine* e, double lr, int64_t n_steps, uint64_t
     ENG_HIP(hipSetDevice(e->desc.device));
     const int ub = history_model(e->desc.model) ? e->user_batch : 1;
     int64_t chunk = std::min(e->chunk, n_steps);
-    if (ub > 1 || e->neg_share > 1) chunk = (chunk + 7) & ~(int64_t)7;   // chunks start on a group boundary
+    if (ub > 1 || e->neg_share > 1 || e->pos_share > 1) chunk = (chunk + 7) & ~(int64_t)7;   // chunks start on a group boundary
     // event-major chunks have a Poisson-distributed length: room for 8 standard deviations
     const bool grouped = e->group >= 2 && sgd_runs_supported(e->desc.model) && (e->stale_window == 0 || e->stale_window >= chunk);
-    if (grouped) { if (int rc = ensure_events(e)) return rc; }
+    const bool paired = !grouped && e->pos_share == 2 && sgd_runs_supported(e->desc.model);
+    if (grouped || paired) { if (int rc = ensure_events(e)) return rc; }
     const int64_t cap = grouped ? chunk + 8 * (int64_t)std::sqrt((double)chunk) + 1024 : chunk;
     if (e->tuples_cap < cap) { if (int rc = ensure_tuples(e, cap)) return rc; }
     hipEvent_t a = nullptr, b = nullptr;
@@ -655,6 +683,8 @@ extern "C" int rec_sgd_epoch(rec_engine* e, double lr, int64_t n_steps, uint64_t
         if (e->profile) { ENG_HIP(hipEventCreate(&a)); ENG_HIP(hipEventCreate(&b)); ENG_HIP(hipEventRecord(a, ss)); }
         if (grouped) {
             if (int rc = launch_event_sampler(e->dm, tb, e->tuples_cap, len, o, (uint64_t)c, seed, epoch, e->group_scratch, e->n_drawn_dev, ss)) return rc;
+        } else if (paired) {
+            if (int rc = launch_pair_sampler(e->dm, tb, len, o, seed, epoch, ss)) return rc;
         } else {
             if (int rc = launch_sampler(e->dm, tb, len, o, seed, epoch, ss, ub, history_model(e->desc.model) ? 1 : e->neg_share)) return rc;
         }
@@ -701,7 +731,10 @@ extern "C" int rec_sample_tuples(rec_engine* e, int64_t n, uint64_t seed, uint64
     if (n <= 0) return 0;
     ENG_HIP(hipSetDevice(e->desc.device));
     if (int rc = ensure_tuples(e, n)) return rc;
-    if (int rc = launch_sampler(e->dm, e->tuples, n, 0, seed, epoch, e->st, history_model(e->desc.model) ? e->user_batch : 1, history_model(e->desc.model) ? 1 : e->neg_share)) return rc;
+    if (e->pos_share == 2 && sgd_runs_supported(e->desc.model)) {
+        if (int rc = ensure_events(e)) return rc;
+        if (int rc = launch_pair_sampler(e->dm, e->tuples, n, 0, seed, epoch, e->st)) return rc;
+    } else if (int rc = launch_sampler(e->dm, e->tuples, n, 0, seed, epoch, e->st, history_model(e->desc.model) ? e->user_batch : 1, history_model(e->desc.model) ? 1 : e->neg_share)) return rc;
     ENG_HIP(hipMemcpyAsync(out, e->tuples, sizeof(int4) * n, hipMemcpyDeviceToHost, e->st));
     ENG_HIP(hipStreamSynchronize(e->st));
     return 0;
@@ -850,6 +883,11 @@ extern "C" int rec_set_option(rec_engine* e, const char* name, int64_t value)
     else if (s == "run_hot") { if (value < 1) { rec_set_error("run_hot must be positive"); return -1; } e->run_policy.hot = (int)value; }
     else if (s == "run_hot_atomic") e->run_policy.hot_atomic = value != 0;
     else if (s == "event_phases") { if (value < 0 || e->dm.n_ev > 0) { rec_set_error("event_phases must be >= 0 and set before the first event-major epoch"); return -1; } e->event_phases = (int)value; }
+    else if (s == "share_positive") {
+        if (value != 1 && value != 2) { rec_set_error("share_positive must be 1 or 2"); return -1; }
+        if (value == 2 && (!sgd_runs_supported(e->desc.model) || e->event_phases > 0)) { rec_set_error("share_positive 2 is not available for this model (or with event_phases)"); return -1; }
+        e->pos_share = (int)value;
+    }
     else if (s == "share_negative") { if (value != 1 && value != 2 && value != 4) { rec_set_error("share_negative must be 1, 2 or 4"); return -1; } e->neg_share = (int)value; }
     else if (s == "user_batch") { if (value != 1 && value != 2 && value != 4 && value != 8) { rec_set_error("user_batch must be 1, 2, 4 or 8"); return -1; } e->user_batch = (int)value; }
     else if (s == "run_segment") { if (value < 0) { rec_set_error("run_segment must be >= 0"); return -1; } e->run_segment = value; }

@@ -139,6 +139,85 @@ int launch_sampler(const DevModel& m, int4* tuples, int64_t n, int64_t first_ste
     return 0;
 }
 
+// ------------------------------------------------------------------ pairs of steps that share their positive item
+// One thread draws steps 2p and 2p+1.  The first is drawn as sampler_kernel draws it: owner uniform, then one of the
+// owner's events uniform.  The second is an event of the first one's positive item, taken with the events' own
+// weights 1 / (events of the owner) through the item's alias table: summed over the first step's item this gives
+// every event the probability the first step gives it, so both steps have the reference's distribution and only
+// their joint distribution differs (same positive).  Both take their negative from one stream of candidates, each
+// accepting the first one its own tuple allows.
+template <int MODEL>
+__global__ void __launch_bounds__(256) pair_sampler_kernel(DevModel m, int4* __restrict__ out, int64_t n, int64_t first_step,
+                                                           uint64_t seed, uint64_t epoch)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (2 * p >= n) return;
+    const uint64_t step = (uint64_t)(first_step + 2 * p);
+    Rng rng(seed, epoch, step);
+    const int pick = (int)bounded(rng.next(), (uint32_t)m.n_elig);
+    const int oa = m.elig_identity ? pick : m.elig[pick];
+    const uint4 rec = *reinterpret_cast<const uint4*>(m.owner_rec + (int64_t)oa * 16);
+    const int64_t off = (int64_t)(((uint64_t)rec.y << 32) | rec.x); const int cnt = (int)rec.z;
+    int aux_a = 0, pos;
+    if constexpr (MODEL == REC_MC) pos = m.succ_item[off + bounded(rng.next(), (uint32_t)cnt)];
+    else if constexpr (MODEL == REC_BPRMF) pos = m.seq_item[off + bounded(rng.next(), (uint32_t)cnt)];
+    else { const int q = (int)bounded(rng.next(), (uint32_t)(cnt - 1)); aux_a = m.seq_item[off + q]; pos = m.seq_item[off + q + 1]; }
+    // the partner: an event of `pos`
+    Rng rb(seed ^ 0x5851F42D4C957F2Dull, epoch, step + 1);
+    const int64_t e0 = m.ev_off[pos]; const int ecnt = (int)(m.ev_off[pos + 1] - e0);
+    int ob = oa, aux_b = aux_a;
+    if (ecnt > 0) {
+        int slot = (int)bounded(rb.next(), (uint32_t)ecnt);
+        const float u01 = (float)(rb.next() >> 8) * (1.0f / 16777216.0f);
+        if (!(u01 < m.ev_alias_p[e0 + slot])) slot = m.ev_alias_i[e0 + slot];
+        const int4 ev = m.ev[e0 + slot];
+        ob = ev.x; aux_b = ev.y;
+    }
+    auto rejected = [&](int owner, int item) {
+        if constexpr (MODEL == REC_BPRMF) {
+            if (!filter_may_contain(m.owner_rec, owner, item)) return false;
+            const int64_t c0 = m.clk_off[owner];
+            return sorted_contains(m.clk_item + c0, (int)(m.clk_off[owner + 1] - c0), item);
+        } else if constexpr (MODEL == REC_MC) {
+            if (!filter_may_contain(m.owner_rec, owner, item)) return false;
+            const int64_t s0 = m.sset_off[owner];
+            return sorted_contains(m.sset_item + s0, (int)(m.sset_off[owner + 1] - s0), item);
+        } else {
+            return item == pos;
+        }
+    };
+    Rng rn(seed ^ 0x8CB92BA72F3D8DD7ull, epoch, step >> 1);
+    int neg_a = -1, neg_b = -1;
+    for (int tr = 0; tr < MAX_TRIES && (neg_a < 0 || neg_b < 0); tr++) {
+        const int c = (int)bounded(rn.next(), (uint32_t)m.I);
+        if (neg_a < 0 && !rejected(oa, c)) neg_a = c;
+        if (neg_b < 0 && !rejected(ob, c)) neg_b = c;
+    }
+    if (neg_a < 0) neg_a = 0;
+    if (neg_b < 0) neg_b = 0;
+    constexpr bool THREE = MODEL == REC_BPRMF || MODEL == REC_MC;
+    out[2 * p] = THREE ? make_int4(oa, pos, neg_a, 0) : make_int4(oa, aux_a, pos, neg_a);
+    if (2 * p + 1 < n) out[2 * p + 1] = THREE ? make_int4(ob, pos, neg_b, 0) : make_int4(ob, aux_b, pos, neg_b);
+}
+
+int launch_pair_sampler(const DevModel& m, int4* tuples, int64_t n, int64_t first_step, uint64_t seed, uint64_t epoch, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    if (m.n_elig <= 0) { rec_set_error("no user (or source item) is eligible for sampling"); return -1; }
+    if (m.n_ev <= 0 || !m.ev_off) { rec_set_error("the event index has not been built"); return -1; }
+    if (first_step & 1) { rec_set_error("a launch of the pair sampler starts on an even step"); return -1; }
+    const int64_t pairs = (n + 1) / 2;
+    const dim3 grid((unsigned)((pairs + 255) / 256)), block(256);
+#define PAIR_CASE(M) case M: hipLaunchKernelGGL(pair_sampler_kernel<M>, grid, block, 0, st, m, tuples, n, first_step, seed, epoch); break;
+    switch (m.model) {
+        PAIR_CASE(REC_BPRMF) PAIR_CASE(REC_MC) PAIR_CASE(REC_FPMC) PAIR_CASE(REC_PRME) PAIR_CASE(REC_HRM_AVG) PAIR_CASE(REC_HRM_MAX)
+    default: rec_set_error("the pair sampler is not available for this model"); return -1;
+    }
+#undef PAIR_CASE
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------ event-major sampling
 // The tuple-major sampler draws an owner uniformly and then one of the owner's events (a training
 // position; for MC a transition) uniformly: event e is hit with probability w_e / n_elig per tuple,

@@ -32,8 +32,8 @@ def main():
     seq_off, seq_item, test, val, _ = make_synthetic(args.users, args.items, args.clicks, 7, torch.device("cuda:0"))
     for var in args.variants.split(","):
         # a variant is a '+'-joined list of: "<policy>:<group>[:run_hot:run_hot_atomic:run_shared]", p<policy>, s<stale_window>,
-        # g<global_window>, m<hex atomic mask on top of the hybrid policy>, u<user_batch>, h<hot_count>, e<event_phases>, n<share_negative>
-        mask = stale = gwin = ub = hotc = phases = negshare = None
+        # g<global_window>, m<hex atomic mask on top of the hybrid policy>, u<user_batch>, h<hot_count>, e<event_phases>, n<share_negative>, q<share_positive>
+        mask = stale = gwin = ub = hotc = phases = negshare = posshare = None
         policy, group, rest = -1, 0, []
         for tok in var.split("+"):
             if tok[0] == "s":
@@ -50,6 +50,8 @@ def main():
                 phases = int(tok[1:])
             elif tok[0] == "n":
                 negshare = int(tok[1:])
+            elif tok[0] == "q":
+                posshare = int(tok[1:])
             elif tok[0] == "p":
                 policy = int(tok[1:])
             else:
@@ -77,6 +79,8 @@ def main():
             eng.set_option("event_phases", phases)
         if negshare is not None:
             eng.set_option("share_negative", negshare)
+        if posshare is not None:
+            eng.set_option("share_positive", posshare)
         eng.set_option("chunk", args.chunk)
         for name, v in zip(("run_hot", "run_hot_atomic", "run_shared"), rest):
             eng.set_option(name, v)

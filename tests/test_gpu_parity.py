@@ -547,6 +547,47 @@ def test_steps_sharing_a_negative_are_scattered_once_with_the_sum(model, policy,
     e.close()
 
 
+@pytest.mark.parametrize("model", ["BPRMF", "MC", "FPMC", "PRME", "HRM_avg"])
+def test_pairs_sharing_their_positive_keep_the_reference_distribution(model):
+    """Option share_positive 2: step 2p+1 is another event of step 2p's positive item, drawn with the events' own
+    weights.  Every tuple lies in the support of the reference's sampler, the two steps of a pair share the positive
+    (and nearly always the negative), and the second steps visit the (owner, event) pairs as often as the first."""
+    g, model, co, ci, labels = fixture_case(model, "toy")
+    e = make_engine(g, model, co, ci, labels, F32)
+    seq_off, seq_item, test, val = orc.split(co, ci)
+    tr = [seq_item[seq_off[u]:seq_off[u + 1]].tolist() for u in range(len(co) - 1)]
+    succ = {}
+    for s_ in tr:
+        for a, b in zip(s_[:-1], s_[1:]):
+            succ.setdefault(a, set()).add(b)
+    e.set_option("share_positive", 2)
+    n = 400000
+    T = e.sample_tuples(n, seed=7, epoch=3)
+    assert np.array_equal(T, e.sample_tuples(n, seed=7, epoch=3))
+    three = model in ("BPRMF", "MC")
+    pos = T[:, 1] if three else T[:, 2]
+    neg = T[:, 2] if three else T[:, 3]
+    assert (pos[0::2] == pos[1::2]).all()
+    assert (neg[0::2] == neg[1::2]).mean() > 0.5
+    for a, b, c, d in T[:6000].tolist():
+        if model == "BPRMF":
+            assert b in tr[a] and c not in tr[a]
+        elif model == "MC":
+            assert b in succ[a] and c not in succ[a]
+        else:
+            assert any(x == b and y == c for x, y in zip(tr[a][:-1], tr[a][1:])) and d != c
+    # the same events at the same rates in both halves of the pairs: compare the histograms of (owner, aux, positive)
+    key = T[:, 0].astype(np.int64) * 1000003 + (T[:, 1].astype(np.int64) if three else T[:, 1].astype(np.int64) * 1009 + T[:, 2])
+    ka, ca = np.unique(key[0::2], return_counts=True)
+    kb, cb = np.unique(key[1::2], return_counts=True)
+    allk = np.union1d(ka, kb)
+    fa = np.zeros(len(allk)); fa[np.searchsorted(allk, ka)] = ca
+    fb = np.zeros(len(allk)); fb[np.searchsorted(allk, kb)] = cb
+    z = (fa - fb) / np.sqrt(np.maximum(fa + fb, 1.0))
+    assert np.abs(z).max() < 6.0 and abs(z.mean()) < 0.2, (np.abs(z).max(), z.mean())
+    e.close()
+
+
 @pytest.mark.parametrize("model", TOY_MODELS)
 def test_sampler_support(model):
     """Every drawn tuple lies in the support of the reference's sampler for that model."""
