@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Validation/test AUC and HIT@50 trajectories of the REAL reference (its own oneiteration + AUC, driven through
+oracle/_ref/ref_driver) on the mid-size long-history corpus of oracle/make_mid_corpus.py, K=64: the accuracy
+anchor for the update policies the engine only switches on for large corpora (hybrid scatter, shared negatives,
+pairs of tuples per history walk).  Three srand() seeds per model give the reference's own seed-to-seed spread.
+Writes tests/golden/mid_trajectories.json.  Test infrastructure; needs /root/reference (through oracle/_ref)."""
+import gzip
+import json
+import os
+import shutil
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(os.path.dirname(HERE), "tests", "golden")
+WORK = "/tmp/refwork_mid"
+DRIVER = os.path.join(HERE, "_ref", "ref_driver")
+K = 64
+# model, L, minCount, lambda, bias_reg, relation_reg, alpha, epochs, every
+RUNS = [
+    ("BPRMF", 1, 1, 0.01, 0.01, 0.0, 0.0, 40, 2),
+    ("FPMC", 1, 1, 0.01, 0.0, 0.0, 0.0, 40, 2),
+    ("TransRec", 1, 1, 0.01, 0.01, 0.01, 0.0, 40, 2),
+    ("HRM_avg", 1, 1, 0.01, 0.0, 0.0, 0.0, 40, 2),
+    ("PRME", 1, 1, 0.01, 0.0, 0.0, 0.5, 40, 2),
+    ("MC", 1, 1, 0.01, 0.0, 0.0, 0.0, 40, 2),
+    ("Fossil", 3, 2, 0.01, 0.01, 0.0, 0.0, 40, 4),
+    ("REBUS", 3, 2, 0.01, 0.0, 0.0, -0.6, 40, 4),
+    ("FossilSimple", 1, 1, 0.01, 0.01, 0.0, 0.0, 40, 4),
+]
+SEEDS = (0, 1, 2)
+
+
+def run(job):
+    cfg, seed = job
+    name, L, mc, lam, breg, rreg, alpha, n, c = cfg
+    out = os.path.join(WORK, "out", f"{name}_{seed}")
+    if os.path.exists(out + ".json"):   # finished by an earlier, interrupted invocation
+        return json.load(open(out + ".json"))
+    cmd = [DRIVER, name, "01-Data/mid_clicks.txt", str(K), str(L), str(mc), repr(lam), repr(breg), repr(rreg), repr(alpha),
+           "-", f"traj:{n}:{c}", "0.05", out]
+    r = subprocess.run(cmd, cwd=WORK, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
+                       env=dict(os.environ, REF_SEED=str(seed)))
+    traj = [[float(x) for x in ln.split()[1:]] for ln in r.stderr.split("\n") if ln.startswith("TRAJ")]
+    secs = [float(ln.split()[2]) for ln in r.stderr.split("\n") if ln.startswith("EPOCH")]
+    best = max(traj, key=lambda t: t[1])
+    res = dict(seed=seed, model=name, K=K, L=L, minCount=mc, lam=lam, bias_reg=breg, relation_reg=rreg, alpha=alpha, epochs=n,
+               every=c, best_iter=int(best[0]), best_auc_val=best[1], auc_test_at_best=best[2], hit50_val_at_best=best[3],
+               hit50_test_at_best=best[4], trajectory=traj, sec_per_epoch=round(sum(secs) / max(1, len(secs)), 3))
+    print(name, "seed", seed, "best", best, flush=True)
+    with open(os.path.join(WORK, "out", f"{name}_{seed}.json"), "w") as f:
+        json.dump(res, f)
+    return res
+
+
+if __name__ == "__main__":
+    if os.environ.get("MID_FRESH", "0") != "0":
+        shutil.rmtree(WORK, ignore_errors=True)
+    for d in ("01-Data", "96-FSUB", "out"):
+        os.makedirs(os.path.join(WORK, d), exist_ok=True)
+    with gzip.open(os.path.join(GOLD, "mid_clicks.txt.gz"), "rb") as f, open(os.path.join(WORK, "01-Data", "mid_clicks.txt"), "wb") as g:
+        g.write(f.read())
+    with gzip.open(os.path.join(GOLD, "mid_clicks_root_fsub_minCount_2_L_3.txt.gz"), "rb") as f, \
+            open(os.path.join(WORK, "96-FSUB", "mid_clicks_root_fsub_minCount_2_L_3.txt"), "wb") as g:
+        g.write(f.read())
+    with ThreadPoolExecutor(int(os.environ.get("MID_WORKERS", "5"))) as ex:
+        results = list(ex.map(run, [(cfg, seed) for cfg in RUNS for seed in SEEDS]))
+    with open(os.path.join(GOLD, "mid_trajectories.json"), "w") as f:
+        json.dump(results, f, indent=0)

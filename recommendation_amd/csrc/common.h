@@ -183,4 +183,17 @@ __device__ __forceinline__ bool sorted_contains(const int32_t* a, int n, int32_t
     }
     return lo < n && a[lo] == x;
 }
+// the k-th (0-based) integer of [0, ...) that is not in the sorted array a[0..n) of distinct values.  With k uniform
+// in [0, I - n) it is a uniform draw from the complement of the set: what a rejection loop converges to, without
+// the loop (used when that loop has run out of tries).
+__device__ __forceinline__ int kth_nonmember(const int32_t* a, int n, int k)
+{
+    // the number of non-members below a[i] is a[i] - i (non-decreasing in i): find the first i with a[i] - i > k
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] - mid > k) hi = mid; else lo = mid + 1;
+    }
+    return k + lo;
+}
 #endif

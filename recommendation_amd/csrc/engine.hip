@@ -184,7 +184,9 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
             bool ok = false;
             switch (d->model) {
             case REC_BPRMF: ok = nd > 0 && nd < I; break;                                   // BPRMF.cpp:78
-            case REC_HRM_AVG: case REC_HRM_MAX: case REC_TRANSREC: case REC_TRANSREC_L1: ok = nd >= 2; break;  // HRM_avg.cpp:130, TransRec.cpp:166
+            case REC_HRM_AVG: case REC_HRM_MAX: ok = nd >= 2; break;                         // HRM_avg.cpp:130
+            // TransRec.cpp:166; a user who clicked the whole catalog has no negative (the reference's draw would never end)
+            case REC_TRANSREC: case REC_TRANSREC_L1: ok = nd >= 2 && nd < I; break;
             default: ok = nu >= 2; break;                                                   // FPMC.cpp:81, PRME.cpp:75, Fossil.cpp:123, REBUS.cpp:275
             }
             if (ok) elig.push_back(u);
@@ -301,7 +303,7 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     // within 0.003 for launches of 2^16 .. 3*10^7 tuples), and longer launches lose less to ramp-up and tails
     if (d->model == REC_TRANSREC || d->model == REC_TRANSREC_L1) e->global_window = 1 << 22;
     // scatter policy: exact sums for small problems, the hybrid for large ones (see rec_set_option)
-    rec_set_option(e, "update_policy", e->steps_per_epoch >= (1 << 22) ? 1 : 0);
+    if (int orc = rec_set_option(e, "update_policy", e->steps_per_epoch >= (1 << 22) ? 1 : 0)) return fail(orc);
     // The history models walk a user's history once for two tuples of that user.  Measured on a 200k-user corpus with
     // ~100 clicks per user: 1.3x (REBUS) / 1.8x (Fossil, FossilSimple) the throughput; early-stopped test AUC equal within
     // run-to-run noise (lr 0.01: 0.8125 vs 0.8124; lr 0.05, REBUS: 0.7794 vs 0.7789).  Both tuples step from the same

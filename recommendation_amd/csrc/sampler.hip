@@ -22,7 +22,9 @@ struct Rng {
     }
 };
 
-#define MAX_TRIES 4096  // every rejection loop ends after this many draws
+#define MAX_TRIES 4096  // every rejection loop ends after this many draws; owners whose set leaves almost nothing to
+                        // draw (a user who clicked nearly the whole catalog) then take the item of uniform rank among the
+                        // non-members of their sorted set - the distribution the reference's unbounded loop converges to
 
 template <int MODEL>
 __global__ void __launch_bounds__(256) sampler_kernel(DevModel m, int4* __restrict__ out, int64_t n, int64_t first_step,
@@ -52,8 +54,9 @@ __global__ void __launch_bounds__(256) sampler_kernel(DevModel m, int4* __restri
             const int64_t s0 = m.sset_off[e];
             return sorted_contains(m.sset_item + s0, (int)(m.sset_off[e + 1] - s0), item);
         };
-        NEG_STREAM; int neg = 0;
-        for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (!successor(neg)) break; }
+        NEG_STREAM; int neg = -1;
+        for (int tr = 0; tr < MAX_TRIES && neg < 0; tr++) { const int c = (int)bounded(rng.next(), (uint32_t)m.I); if (!successor(c)) neg = c; }
+        if (neg < 0) { const int64_t s0 = m.sset_off[e]; const int ns = (int)(m.sset_off[e + 1] - s0); neg = kth_nonmember(m.sset_item + s0, ns, (int)bounded(rng.next(), (uint32_t)(m.I - ns))); }
         t = make_int4(e, pos, neg, 0);
     } else {
         const uint4 rec = *reinterpret_cast<const uint4*>(m.owner_rec + (int64_t)e * 16);
@@ -65,11 +68,16 @@ __global__ void __launch_bounds__(256) sampler_kernel(DevModel m, int4* __restri
             const int64_t c0 = m.clk_off[e];
             return sorted_contains(m.clk_item + c0, (int)(m.clk_off[e + 1] - c0), item);
         };
+        auto unclicked_of_rank = [&](uint32_t r) {
+            const int64_t c0 = m.clk_off[e]; const int nc = (int)(m.clk_off[e + 1] - c0);
+            return kth_nonmember(m.clk_item + c0, nc, (int)bounded(r, (uint32_t)(m.I - nc)));
+        };
         if constexpr (MODEL == REC_BPRMF) {
             // BPRMF.cpp:74-83, 135-143
             const int pos = seq[bounded(rng.next(), (uint32_t)nu)];
-            NEG_STREAM; int neg = 0;
-            for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (!clicked(neg)) break; }
+            NEG_STREAM; int neg = -1;
+            for (int tr = 0; tr < MAX_TRIES && neg < 0; tr++) { const int c = (int)bounded(rng.next(), (uint32_t)m.I); if (!clicked(c)) neg = c; }
+            if (neg < 0) neg = unclicked_of_rank(rng.next());
             t = make_int4(e, pos, neg, 0);
         } else if constexpr (MODEL == REC_FPMC || MODEL == REC_PRME || MODEL == REC_FOSSIL_SIMPLE || MODEL == REC_HRM_AVG ||
                              MODEL == REC_HRM_MAX) {
@@ -85,8 +93,9 @@ __global__ void __launch_bounds__(256) sampler_kernel(DevModel m, int4* __restri
         } else if constexpr (MODEL == REC_TRANSREC || MODEL == REC_TRANSREC_L1) {
             // TransRec.cpp:188-199
             const int p = (int)bounded(rng.next(), (uint32_t)(nu - 1));
-            NEG_STREAM; int neg = 0;
-            for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (!clicked(neg)) break; }
+            NEG_STREAM; int neg = -1;
+            for (int tr = 0; tr < MAX_TRIES && neg < 0; tr++) { const int c = (int)bounded(rng.next(), (uint32_t)m.I); if (!clicked(c)) neg = c; }
+            if (neg < 0) neg = unclicked_of_rank(rng.next());
             t = make_int4(e, seq[p], seq[p + 1], neg);
         } else if constexpr (MODEL == REC_FOSSIL) {
             // Fossil.cpp:282-293: target position 1..nu-1, negative outside {pos} + the <= L previous items
@@ -193,8 +202,20 @@ __global__ void __launch_bounds__(256) pair_sampler_kernel(DevModel m, int4* __r
         if (neg_a < 0 && !rejected(oa, c)) neg_a = c;
         if (neg_b < 0 && !rejected(ob, c)) neg_b = c;
     }
-    if (neg_a < 0) neg_a = 0;
-    if (neg_b < 0) neg_b = 0;
+    auto fallback = [&](int owner) {
+        if constexpr (MODEL == REC_BPRMF) {
+            const int64_t c0 = m.clk_off[owner]; const int nc = (int)(m.clk_off[owner + 1] - c0);
+            return kth_nonmember(m.clk_item + c0, nc, (int)bounded(rn.next(), (uint32_t)(m.I - nc)));
+        } else if constexpr (MODEL == REC_MC) {
+            const int64_t s0 = m.sset_off[owner]; const int ns = (int)(m.sset_off[owner + 1] - s0);
+            return kth_nonmember(m.sset_item + s0, ns, (int)bounded(rn.next(), (uint32_t)(m.I - ns)));
+        } else {
+            const int c = (int)bounded(rn.next(), (uint32_t)(m.I - 1));   // uniform over the catalog without pos
+            return c >= pos ? c + 1 : c;
+        }
+    };
+    if (neg_a < 0) neg_a = fallback(oa);
+    if (neg_b < 0) neg_b = fallback(ob);
     constexpr bool THREE = MODEL == REC_BPRMF || MODEL == REC_MC;
     out[2 * p] = THREE ? make_int4(oa, pos, neg_a, 0) : make_int4(oa, aux_a, pos, neg_a);
     if (2 * p + 1 < n) out[2 * p + 1] = THREE ? make_int4(ob, pos, neg_b, 0) : make_int4(ob, aux_b, pos, neg_b);
@@ -334,11 +355,15 @@ __global__ void __launch_bounds__(256) event_emit_kernel(DevModel m, int4* __res
         int4 t;
         if constexpr (MODEL == REC_BPRMF) {
             const int32_t* clk = m.clk_item + m.clk_off[ev.x]; const int nc = (int)(m.clk_off[ev.x + 1] - m.clk_off[ev.x]);
-            for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (!filter_may_contain(m.owner_rec, ev.x, neg) || !sorted_contains(clk, nc, neg)) break; }
+            neg = -1;
+            for (int tr = 0; tr < MAX_TRIES && neg < 0; tr++) { const int c = (int)bounded(rng.next(), (uint32_t)m.I); if (!filter_may_contain(m.owner_rec, ev.x, c) || !sorted_contains(clk, nc, c)) neg = c; }
+            if (neg < 0) neg = kth_nonmember(clk, nc, (int)bounded(rng.next(), (uint32_t)(m.I - nc)));
             t = make_int4(ev.x, ev.z, neg, 0);
         } else if constexpr (MODEL == REC_MC) {
             const int32_t* ss = m.sset_item + m.sset_off[ev.x]; const int ns = (int)(m.sset_off[ev.x + 1] - m.sset_off[ev.x]);
-            for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (!filter_may_contain(m.owner_rec, ev.x, neg) || !sorted_contains(ss, ns, neg)) break; }
+            neg = -1;
+            for (int tr = 0; tr < MAX_TRIES && neg < 0; tr++) { const int c = (int)bounded(rng.next(), (uint32_t)m.I); if (!filter_may_contain(m.owner_rec, ev.x, c) || !sorted_contains(ss, ns, c)) neg = c; }
+            if (neg < 0) neg = kth_nonmember(ss, ns, (int)bounded(rng.next(), (uint32_t)(m.I - ns)));
             t = make_int4(ev.x, ev.z, neg, 0);
         } else {
             for (int tr = 0; tr < MAX_TRIES; tr++) { neg = (int)bounded(rng.next(), (uint32_t)m.I); if (neg != ev.z) break; }

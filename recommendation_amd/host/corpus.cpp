@@ -158,9 +158,10 @@ void corpus::loadClicks(const char* clickFile, int userMin, int itemMin)
     printf("\n  Sorting clicks for each users ");
 #pragma omp parallel for schedule(dynamic, 1024)
     for (int u = 0; u < nUsers; u++) {
-        // the reference's std::sort is unstable on equal timestamps (src/corpus.cpp:219); a stable sort is one of its valid outcomes
-        std::stable_sort(pos_per_user[u].begin(), pos_per_user[u].end(),
-                         [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.second < b.second; });
+        // std::sort with the reference's comparator on the same input order (src/corpus.cpp:4-7, 219): it is unstable
+        // on equal timestamps, and with the same libstdc++ introsort the permutation of tied clicks is the reference's
+        std::sort(pos_per_user[u].begin(), pos_per_user[u].end(),
+                  [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.second < b.second; });
     }
     printf("\n");
 }

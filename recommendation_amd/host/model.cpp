@@ -83,6 +83,7 @@ void model::createEngine(rec_model_desc desc, const vector<int64_t>* path_off, c
     const char* dv = getenv("RECSYS_DEVICE");
     desc.device = dv ? atoi(dv) : 0;
     desc.user_begin = desc.user_end = 0;
+    best_on_device = false;
     check(rec_create(&c, &desc, &eng));
     NW = (int)rec_nw(eng);
     W = new double[NW > 0 ? NW : 1];
@@ -92,6 +93,7 @@ void model::createEngine(rec_model_desc desc, const vector<int64_t>* path_off, c
 void model::destroyEngine()
 {
     if (eng) { rec_destroy(eng); eng = 0; }
+    best_on_device = false;
 }
 
 void model::syncToHost() { if (eng && NW > 0) check(rec_params_download(eng, W, NW)); }
@@ -193,6 +195,7 @@ void model::trainLoop(int iterations, double learn_rate, int cadence, int first_
     int best_iter = 0;
     for (int iter = 1; iter <= iterations; iter++) {
         double l_dlStart = clock_();
+        beforeEpoch(iter);
         epoch(learn_rate);
         printf("Iter: %d, took %f\n", iter, clock_() - l_dlStart);
         fflush(stdout);
@@ -216,9 +219,9 @@ void model::trainLoop(int iterations, double learn_rate, int cadence, int first_
             }
         }
     }
-    // "copy back best parameters": without a validation the reference copies an uninitialised bestW;
-    // the device snapshot is zero-filled in that case
-    check(rec_restore_best(eng));
+    // "copy back best parameters" (e.g. BPRMF.cpp:189-191).  Without any validation the reference copies an
+    // uninitialised bestW (undefined behaviour); here the trained parameters are kept instead.
+    if (best_on_device) check(rec_restore_best(eng));
     double AUC_val, AUC_test, HIT_val, HIT_test, MRR_val, MRR_test, var;
     AUC(&AUC_val, &AUC_test, &HIT_val, &HIT_test, &MRR_val, &MRR_test, &var);
     printf("\n\n <<< %s >>> Test AUC = %f, Val AUC = %f, Test var = %f\n", toString().c_str(), AUC_test, AUC_val, var);
@@ -323,12 +326,16 @@ string FossilSimple::toString() { char s[100]; sprintf(s, "FossilSimple__K_%d_la
 void Fossil::init() { createEngine(make_desc(REC_FOSSIL, K, K, L, lambda, bias_reg, 0, 0, dataset_factor)); check(rec_params_init(eng, 0)); }
 void Fossil::cleanUp() { destroyEngine(); delete[] W; delete[] bestW; W = bestW = 0; }
 void Fossil::train(int iterations, double learn_rate) { trainLoop(iterations, learn_rate, 50, 0, 300, false); }
-void Fossil::oneiteration(double learn_rate)
+void Fossil::beforeEpoch(int)
 {
-    // Fossil.cpp:260; W = [beta:I][WT:L]...
+    // the progress line at the top of every Fossil::oneiteration, Fossil.cpp:260; W = [beta:I][WT:L]...
     double wt[2] = {0, 0};
     check(rec_params_read(eng, nItems, L < 2 ? L : 2, wt));
     printf("decay_wt_0 = %f, decay_wt_1 = %f\n", wt[0], wt[1]);
+}
+void Fossil::oneiteration(double learn_rate)
+{
+    beforeEpoch(0);
     epoch(learn_rate);
 }
 void Fossil::updateFactors(int user_id, vector<int>& prev_items, int pos_item_id, int neg_item_id, double learn_rate)

@@ -52,6 +52,7 @@ protected:
     // the shared train() loop of the reference (e.g. src/models/BPRMF.cpp:152-203)
     void trainLoop(int iterations, double learn_rate, int cadence, int first_validation_after, int patience, bool verbose_validation);
     virtual void epoch(double learn_rate);
+    virtual void beforeEpoch(int iter) {}
     virtual void afterEpoch(int iter) {}
     void check(int rc) const;
     unsigned long long epoch_counter;
@@ -178,6 +179,8 @@ public:
     // prev_items must be the (at most L) items before the target position, newest first, as oneiteration builds them
     void updateFactors(int user_id, std::vector<int>& prev_items, int pos_item_id, int neg_item_id, double learn_rate);
     int L, K; double lambda, bias_reg; int dataset_factor;
+protected:
+    void beforeEpoch(int iter);
 };
 
 class REBUS : public model

@@ -111,3 +111,23 @@ def test_corpus_cache_round_trip(tmp_path):
     assert open(tmp_path / "96-FSUB" / "out0.txt").read() == open(tmp_path / "96-FSUB" / "out1.txt").read()
     line = lambda o: [x for x in o.split("\n") if '"nUsers"' in x][0]
     assert line(outs[0]) == line(outs[1])
+
+
+def test_loader_orders_tied_clicks_as_the_reference(tmp_path):
+    """Users with up to 70 clicks and many equal time stamps, whitespace and .csv form: ids and per-user order equal the
+    corpus the reference's loader built from the same files (its std::sort is unstable, src/corpus.cpp:219; the dump
+    was written by oracle/make_ties_golden.py through the real reference)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "recommendation_amd", "corpus_dump")
+    assert os.path.exists(tool), "build recommendation_amd/host first"
+    gold = np.load(os.path.join(root, "tests", "golden", "ties_corpus.npz"))
+    for ext in ("txt", "csv"):
+        shutil.copy(os.path.join(root, "tests", "golden", f"ties_clicks.{ext}"), tmp_path / f"ties.{ext}")
+        r = subprocess.run([tool, str(tmp_path / f"ties.{ext}"), "0", "0"], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stderr
+        got = np.array(r.stdout.split(), np.int64)
+        assert np.array_equal(got, gold[f"corpus_{ext}"].astype(np.int64)), ext
+    lens = gold["corpus_txt"]
+    assert lens[0] == 60 and lens[2] == 2031

@@ -104,3 +104,20 @@ def test_rebus_run(workdir):
     assert len(saved) == 1 and len(parse_saved(workdir / "03-Models" / saved[0])) == 31339
     out = run(workdir, f"01-Data/{ML5}.txt", 0, 0, 7, 7, 10, 0.01, 0, 0, -0.6, 1, "03-Models/r", "REBUS")
     assert "No substrings found for the dataset" in out
+
+
+@pytest.mark.gpu
+def test_run_shorter_than_the_first_validation_keeps_the_trained_model(workdir):
+    """10 iterations: no validation ever runs (cadence 50), so there is no best snapshot to copy back
+    (the reference copies an uninitialised bestW here, BPRMF.cpp:189-191).  The trained parameters must be
+    what is evaluated and saved."""
+    out = run(workdir, f"01-Data/{ML5}.txt", 0, 0, 1, 1, 10, 0.01, 0.01, 0, 0, 10, "03-Models/s", "BPRMF")
+    assert "[Valid AUC" not in out
+    W = parse_saved(workdir / "03-Models" / "s__BPR-MF__K_10_lambda_0.010000_biasReg_0.010000.txt")
+    assert np.count_nonzero(W) > 0.9 * len(W)
+    g, model, co, ci, labels = fixture_case("BPRMF", "ml5")
+    _, counts = make_oracle(g, model, co, ci, labels).eval(W)
+    mm = orc.metrics(counts)
+    m = re.search(r"Test AUC = ([0-9.]+), Val AUC = ([0-9.]+)", out)
+    assert abs(float(m.group(1)) - mm[1]) < 2e-4 and abs(float(m.group(2)) - mm[0]) < 2e-4
+    assert float(m.group(1)) > 0.55
