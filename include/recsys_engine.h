@@ -103,6 +103,14 @@ int rec_restore_best(rec_engine* e);
  *   TransRec* (u,x,y,yn)  Fossil (u,t,neg,-) and REBUS (u,t-1,neg,-) with target seq[u][t] */
 int rec_sgd_replay(rec_engine* e, double lr, const int32_t* tuples, int64_t n, int mode);
 
+/* No counterpart in the reference.  rec_sgd_replay for callers that cannot allocate device memory (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc): the same kernels, with the tuples staged in
+ * a fixed 1 MiB device array that is part of the library's code object instead of a buffer grown on demand.  It calls
+ * no hipMalloc / hipFree and creates no HIP events ("profile" does not time it).  n <= 65536 tuples per call; larger
+ * n is rejected with an error.  Every engine on one GPU shares that GPU's array: calls (of any engines) that overlap
+ * on one GPU race.  Results are those of rec_sgd_replay on the same tuples. */
+int rec_sgd_replay_static(rec_engine* e, double lr, const int32_t* tuples, int64_t n, int mode);
+
 /* replaces: <Model>::oneiteration / oneIteration (e.g. BPRMF.cpp:107-150): n_steps tuples drawn on
  * the device by a counter-based generator keyed by (seed, epoch, step), applied Hogwild-style */
 int rec_sgd_epoch(rec_engine* e, double lr, int64_t n_steps, uint64_t seed, uint64_t epoch);

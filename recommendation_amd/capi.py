@@ -13,7 +13,7 @@ F32, F64 = 0, 1
 SEQUENTIAL, HOGWILD = 0, 1
 
 EXPORTS = ["rec_last_error", "rec_create", "rec_destroy", "rec_sync", "rec_nw", "rec_params_upload",
-           "rec_params_download", "rec_params_read", "rec_params_init", "rec_snapshot_best", "rec_restore_best", "rec_sgd_replay",
+           "rec_params_download", "rec_params_read", "rec_params_init", "rec_snapshot_best", "rec_restore_best", "rec_sgd_replay", "rec_sgd_replay_static",
            "rec_sgd_epoch", "rec_sample_tuples", "rec_sample_events", "rec_tuples_drawn", "rec_steps_per_epoch", "rec_eval", "rec_eval_sampled", "rec_eval_topk", "rec_eval_sums",
            "rec_rebus_build_paths", "rec_fsub_mine", "rec_num_tables", "rec_table_info", "rec_set_option", "rec_kernel_stats"]
 
@@ -174,6 +174,12 @@ class Engine:
         tuples = np.ascontiguousarray(tuples, np.int32)
         assert tuples.ndim == 2 and tuples.shape[1] == 4
         _check(lib().rec_sgd_replay(self.handle, C.c_double(lr), _p(tuples), C.c_int64(len(tuples)), C.c_int(mode)))
+
+    def sgd_replay_static(self, lr, tuples, mode=SEQUENTIAL):
+        """rec_sgd_replay without any device allocation (at most 65536 tuples per call)."""
+        tuples = np.ascontiguousarray(tuples, np.int32)
+        assert tuples.ndim == 2 and tuples.shape[1] == 4
+        _check(lib().rec_sgd_replay_static(self.handle, C.c_double(lr), _p(tuples), C.c_int64(len(tuples)), C.c_int(mode)))
 
     def sgd_epoch(self, lr, n_steps, seed, epoch):
         _check(lib().rec_sgd_epoch(self.handle, C.c_double(lr), C.c_int64(n_steps), C.c_uint64(seed), C.c_uint64(epoch)))

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <math.h>
 #include <string.h>
+#include <mutex>
 #include <vector>
 
 static thread_local std::string g_err;
@@ -37,6 +38,7 @@ struct rec_engine {
     hipEvent_t ev_sampled[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
     bool consumed_valid[2] = {false, false};
     std::vector<void*> owned;
+    std::vector<int64_t> seq_off_host;  // host copy of the training sequence offsets (replay argument checks)
     // options
     int64_t chunk = 1 << 26;
     int overlap = 0;     // 1: the sampler of chunk c+1 runs on a second stream next to the update of chunk c
@@ -57,6 +59,28 @@ struct rec_engine {
     int64_t launches[4] = {0, 0, 0, 0};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[4];
 };
+
+// Tuple staging of rec_sgd_replay_static: lives in the code object, so that entry point never allocates.  One copy per
+// GPU the library runs on (1 MiB each, held until the process ends); its address on a device is looked up once, in
+// rec_create, with that device current.  In host code the array's name is only a handle for that lookup.
+#define REC_STATIC_MAX_TUPLES 65536
+static __device__ __align__(256) int4 scratch[REC_STATIC_MAX_TUPLES];
+#define REC_MAX_DEVICES 64
+static int4* g_scratch_ptr[REC_MAX_DEVICES];   // per device: where `scratch` lives there (nullptr = not looked up yet)
+static std::mutex g_scratch_mutex;
+
+// with device `dev` current
+static int lookup_scratch(int dev)
+{
+    if (dev < 0 || dev >= REC_MAX_DEVICES) { rec_set_error("device ordinal beyond the static scratch table"); return -1; }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[dev]) return 0;
+    void* ptr = nullptr;
+    hipError_t rc = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (rc != hipSuccess || !ptr) { rec_set_error(std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(rc)); return -2; }
+    g_scratch_ptr[dev] = (int4*)ptr;
+    return 0;
+}
 
 static int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
@@ -118,6 +142,7 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     ENG_HIP(hipGetDeviceCount(&ndev));
     if (d->device < 0 || d->device >= ndev) { rec_set_error("no such HIP device"); return -1; }
     ENG_HIP(hipSetDevice(d->device));
+    if (int rc = lookup_scratch(d->device)) return rc;
 
     rec_engine* e = new rec_engine();
     e->desc = *d;
@@ -136,6 +161,7 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     const int L = e->desc.L;
     // ---- host-side derived structures
     std::vector<int64_t> seq_off(c->seq_off, c->seq_off + U + 1);
+    e->seq_off_host = seq_off;
     std::vector<int32_t> seq_item(c->seq_item, c->seq_item + E);
     std::vector<int32_t> test_item(c->test_item, c->test_item + U), val_item(c->val_item, c->val_item + U);
     for (int64_t p = 0; p < E; p++)
@@ -611,28 +637,24 @@ static int check_tuples(const rec_engine* e, const int32_t* t, int64_t n)
     return 0;
 }
 
-extern "C" int rec_sgd_replay(rec_engine* e, double lr, const int32_t* tuples, int64_t n, int mode)
+// dev_buf: device room for the n tuples (the engine's own chunk buffer, or the static scratch); timed: HIP events
+// around every launch when "profile" is on (creating events allocates)
+static int replay_tuples(rec_engine* e, double lr, const int32_t* tuples, int64_t n, int mode, int4* dev_buf, bool timed)
 {
-    if (!e || (!tuples && n > 0)) { rec_set_error("null argument"); return -1; }
-    if (e->desc.model == REC_MP) { rec_set_error("MostPopular has nothing to train"); return -1; }
-    if (n <= 0) return 0;
-    ENG_HIP(hipSetDevice(e->desc.device));
     if (int rc = check_tuples(e, tuples, n)) return rc;
     if (e->desc.model == REC_FOSSIL || e->desc.model == REC_REBUS) {
         // target positions must lie inside the user's training sequence
-        std::vector<int64_t> so(e->U + 1);
-        ENG_HIP(hipMemcpy(so.data(), e->dm.seq_off, sizeof(int64_t) * (e->U + 1), hipMemcpyDeviceToHost));
+        const std::vector<int64_t>& so = e->seq_off_host;
         for (int64_t i = 0; i < n; i++) {
             const int u = tuples[4 * i]; const int64_t nu = so[u + 1] - so[u];
             const int64_t tp = tuples[4 * i + 1] + (e->desc.model == REC_REBUS ? 1 : 0);
             if (tp < 1 || tp >= nu) { rec_set_error("tuple " + std::to_string(i) + ": target position out of range"); return -1; }
         }
     }
-    if (int rc = ensure_tuples(e, n)) return rc;
-    ENG_HIP(hipMemcpyAsync(e->tuples, tuples, sizeof(int4) * n, hipMemcpyHostToDevice, e->st));
+    ENG_HIP(hipMemcpyAsync(dev_buf, tuples, sizeof(int4) * n, hipMemcpyHostToDevice, e->st));
     hipEvent_t a = nullptr, b = nullptr;
     if (mode == REC_REPLAY_SEQUENTIAL) {
-        if (int rc = launch_sgd_sequential(e->dm, e->desc.precision, e->tuples, n, lr, e->st)) return rc;
+        if (int rc = launch_sgd_sequential(e->dm, e->desc.precision, dev_buf, n, lr, e->st)) return rc;
         ENG_HIP(hipStreamSynchronize(e->st));
     } else if (mode == REC_REPLAY_HOGWILD) {
         // the batched history kernel takes every aligned group of user_batch tuples as one user's: tuples that do not
@@ -644,9 +666,9 @@ extern "C" int rec_sgd_replay(rec_engine* e, double lr, const int32_t* tuples, i
         if (ub > 1 || e->neg_share > 1 || e->pos_share > 1) chunk = std::max<int64_t>(8, chunk & ~(int64_t)7);
         for (int64_t o = 0; o < n; o += chunk) {
             const int64_t len = std::min(chunk, n - o);
-            if (int rc = ev_begin(e, 0, &a, &b)) return rc;
-            if (int rc = launch_update(e, e->tuples + o, len, lr, false, ub)) return rc;
-            if (int rc = ev_end(e, 0, a, b)) return rc;
+            if (timed) { if (int rc = ev_begin(e, 0, &a, &b)) return rc; }
+            if (int rc = launch_update(e, dev_buf + o, len, lr, false, ub)) return rc;
+            if (timed) { if (int rc = ev_end(e, 0, a, b)) return rc; }
         }
         // the host buffer may be reused by the caller: the copy above must have completed
         ENG_HIP(hipStreamSynchronize(e->st));
@@ -654,6 +676,31 @@ extern "C" int rec_sgd_replay(rec_engine* e, double lr, const int32_t* tuples, i
         rec_set_error("unknown replay mode"); return -1;
     }
     return 0;
+}
+
+extern "C" int rec_sgd_replay(rec_engine* e, double lr, const int32_t* tuples, int64_t n, int mode)
+{
+    if (!e || (!tuples && n > 0)) { rec_set_error("null argument"); return -1; }
+    if (e->desc.model == REC_MP) { rec_set_error("MostPopular has nothing to train"); return -1; }
+    if (n <= 0) return 0;
+    ENG_HIP(hipSetDevice(e->desc.device));
+    if (int rc = ensure_tuples(e, n)) return rc;
+    return replay_tuples(e, lr, tuples, n, mode, e->tuples, true);
+}
+
+extern "C" int rec_sgd_replay_static(rec_engine* e, double lr, const int32_t* tuples, int64_t n, int mode)
+{
+    if (!e || (!tuples && n > 0)) { rec_set_error("null argument"); return -1; }
+    if (e->desc.model == REC_MP) { rec_set_error("MostPopular has nothing to train"); return -1; }
+    if (n <= 0) return 0;
+    if (n > REC_STATIC_MAX_TUPLES) { rec_set_error("rec_sgd_replay_static takes at most " + std::to_string(REC_STATIC_MAX_TUPLES) + " tuples per call"); return -1; }
+    ENG_HIP(hipSetDevice(e->desc.device));
+    int4* buf = g_scratch_ptr[e->desc.device];   // looked up by rec_create on this device
+    if (!buf) { rec_set_error("the static scratch of this device has not been looked up"); return -2; }
+    // work enqueued earlier on either stream may still read the engine's own buffers, never this one; calls on one
+    // engine do not overlap, and this call returns only after its kernels have finished
+    ENG_HIP(hipStreamSynchronize(e->st2));
+    return replay_tuples(e, lr, tuples, n, mode, buf, false);
 }
 
 extern "C" int rec_sgd_epoch(rec_engine* e, double lr, int64_t n_steps, uint64_t seed, uint64_t epoch)
