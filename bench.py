@@ -12,11 +12,15 @@ applies 1/N of the epoch's tuples to its own users, and the item tables are comb
 step with an RCCL all-reduce of the per-rank deltas (total work fixed: strong scaling).
 Evaluation is sharded by user; the metric sums are all-reduced.
 
-One JSON line on stdout (rank 0).  `roofline` prices the update kernel against HBM with the
-algorithmic bytes per triple (each of the 3 K-float rows and 2 biases read once and written once =
-1552 B) and the kernel's average duration from HIP events on the engine's stream; `cpu_baseline`
-times BPRMF::oneiteration of the reference binary built under oracle/_ref on a user sample of the
-same corpus (`cpu_port`: the single-thread CPU restatement on the whole corpus).
+One JSON line on stdout (rank 0).  `roofline` prices the update kernel of the engine's defaults (the
+reference's sampling: every step draws its own negative) against HBM with the algorithmic bytes per
+triple (each distinct row and bias a step names read once and written once: 3 K-float rows + 2 biases
+= 1552 B for BPRMF K=64 f32) and the kernel's average duration from HIP events on the engine's stream;
+`variants` (N=1 only) holds the same measurement for the other scatter modes and for f64 storage;
+`cpu_baseline` times BPRMF::oneiteration of the reference binary built under oracle/_ref on a user sample
+of the same corpus (`cpu_port`: the single-thread CPU restatement on the whole corpus); `eval.cpu_baseline`
+times the reference binary's own model::AUC on a user sample over the full catalog.
+`roofline.traffic` is null: HBM bytes come from rocprofv3 --pmc passes (profiles/), never from this run.
 """
 import argparse
 import json
@@ -127,6 +131,46 @@ def _time_reference(args, seq_off, seq_item, test_item, val_item, K):
         shutil.rmtree(work, ignore_errors=True)
 
 
+def _time_reference_eval(args, seq_off, seq_item, test_item, val_item, K, I):
+    """model::AUC of the reference binary (oracle/_ref/ref_driver, BPRMF) on the first --cpu-ref-eval-users users of the
+    corpus ranked against the whole catalog: the click file holds those users plus two-click filler users (never
+    evaluated: model.hpp:22-31 needs three clicks) that bring every item of the catalog into the corpus."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    if args.cpu_ref_eval_users <= 0 or not os.path.exists(exe):
+        return None
+    nu = min(args.cpu_ref_eval_users, len(seq_off) - 1)
+    work = tempfile.mkdtemp(prefix="recsys_refeval_")
+    try:
+        os.makedirs(os.path.join(work, "01-Data"))
+        path = os.path.join(work, "01-Data", "sample.txt")
+        rows = []
+        for u in range(nu):
+            a, b = int(seq_off[u]), int(seq_off[u + 1])
+            its = list(seq_item[a:b]) + [int(val_item[u]), int(test_item[u])]
+            rows += [(u, int(i), 1, t) for t, i in enumerate(its)]
+        filler = np.arange(I + (I & 1))
+        filler[-1] = min(filler[-1], I - 1)
+        for k in range(len(filler) // 2):
+            rows += [(nu + k, int(filler[2 * k]), 1, 0), (nu + k, int(filler[2 * k + 1]), 1, 1)]
+        np.savetxt(path, np.array(rows, np.int64), fmt="%d")
+        r = subprocess.run([exe, "BPRMF", "01-Data/sample.txt", str(K), "1", "1", "0.01", "0.01", "0", "0", "-", "traj:1:1",
+                            "0.05", os.path.join(work, "out")], cwd=work, capture_output=True, text=True, timeout=900)
+        secs = [float(x) for x in re.findall(r"EVALSEC \d+ ([0-9.]+)", r.stderr + r.stdout)]
+        if r.returncode != 0 or not secs:
+            return None
+        return {"value": round(nu / secs[0], 2), "unit": "users/s", "cores": 1, "kind": "reference",
+                "sample": f"model::AUC of the reference binary on the first {nu} users of the same corpus, all {I} items, "
+                          f"K={K}, fp64, {secs[0]:.1f} s"}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,7 +191,12 @@ def main():
     ap.add_argument("--share-positive", type=int, default=0, help="share_positive of the group models (1, 2); 0 = engine default")
     ap.add_argument("--share-negative", type=int, default=0, help="share_negative of the group models (1, 2); 0 = engine default")
     ap.add_argument("--user-batch", type=int, default=0, help="user_batch of the history models (1, 2, 4, 8); 0 = engine default")
-    ap.add_argument("--eval-users", type=int, default=0, help="evaluate only the first n users of each shard (0 = all)")
+    ap.add_argument("--owner", type=int, default=-1, help="owner_neg: negatives' deltas summed in LDS by the workgroup that owns their slice of the catalog (0, 1); -1 = engine default")
+    ap.add_argument("--owner-flush", type=int, default=0, help="owner_flush (additions per atomic row); 0 = engine default")
+    ap.add_argument("--cpu-ref-eval-users", type=int, default=1000, help="users the reference binary's model::AUC is timed on (0 = skip)")
+    ap.add_argument("--wide", type=int, default=-1, help="wide: the four-components-per-lane form of the update kernel (0, 1); -1 = engine default")
+    ap.add_argument("--atomic-mask", type=int, default=-1, help="experiment: the engine's 'atomic' row mask (bit r = row r of the tuple, bit 8 = biases)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra measurements of the other scatter modes and of f64 storage")
     ap.add_argument("--cpu-eval-users", type=int, default=16384, help="users of the CPU evaluation baseline (0 = skip)")
     ap.add_argument("--cpu-ref-users", type=int, default=60000, help="users of the click file the reference binary is timed on (0 = skip)")
     ap.add_argument("--cpu-steps", type=int, default=12_000_000, help="tuples of the CPU baseline sample (0 = skip)")
@@ -193,10 +242,6 @@ def main():
     U, I, K = args.users, args.items, args.k
     from recommendation_amd.dist_util import combine_item_tables, shard_range
     ub, ue = shard_range(U, rank, world)
-    if args.eval_users:
-        # a shard that evaluates fewer users still trains on all of its users: two engines would be
-        # needed; the bench keeps one engine and simply reports the users it evaluated
-        pass
     prec = F32 if args.precision == "f32" else F64
     esz = 4 if prec == F32 else 8
     def stage(msg):
@@ -217,107 +262,171 @@ def main():
                     user_begin=ub, user_end=ue, path_off=po, path_item=pi)
     stage("engine created")
     eng.init_params(seed=2024)
+    GROUP_MODELS = ("BPRMF", "MC", "FPMC", "PRME", "HRM_avg", "HRM_max")
+    HISTORY_MODELS = ("Fossil", "FossilSimple", "REBUS")
+    big = eng.steps_per_epoch >= (1 << 22)
+    # the engine's defaults (rec_create), overridden by the flags
+    mode = {"policy": 1 if big else 0, "owner": 1 if big and args.model in GROUP_MODELS else 0, "owner_flush": 8,
+            "neg_share": 1, "pos_share": 1, "group": 0}
     if args.policy >= 0:
-        eng.set_option("update_policy", args.policy)
-    policy = args.policy if args.policy >= 0 else (1 if eng.steps_per_epoch >= (1 << 22) else 0)
+        eng.set_option("update_policy", args.policy); mode["policy"] = args.policy
     if args.group >= 0:
-        eng.set_option("group_by_item", args.group)
-    grouped = (args.group if args.group >= 0 else 0) == 2 and args.model in ("BPRMF", "MC", "FPMC", "PRME", "HRM_avg", "HRM_max")
+        eng.set_option("group_by_item", args.group); mode["group"] = args.group
     eng.set_option("chunk", args.chunk)
     eng.set_option("overlap", args.overlap)
     if args.user_batch > 0:
         eng.set_option("user_batch", args.user_batch)
     if args.share_negative > 0:
-        eng.set_option("share_negative", args.share_negative)
+        eng.set_option("share_negative", args.share_negative); mode["neg_share"] = args.share_negative
     if args.share_positive > 0:
-        eng.set_option("share_positive", args.share_positive)
-    pos_share = args.share_positive if args.share_positive > 0 else 1
-    # the engine's default: pairs of steps share their negative when an epoch is >= 4M steps (not TransRec, not the history models)
-    neg_share = args.share_negative if args.share_negative > 0 else \
-        (2 if eng.steps_per_epoch >= (1 << 22) and args.model in ("BPRMF", "MC", "FPMC", "PRME", "HRM_avg", "HRM_max") else 1)
+        eng.set_option("share_positive", args.share_positive); mode["pos_share"] = args.share_positive
+    if args.atomic_mask >= 0:
+        eng.set_option("atomic", args.atomic_mask)
+    if args.wide >= 0:
+        eng.set_option("wide", args.wide)
+    if args.owner >= 0:
+        eng.set_option("owner_neg", args.owner); mode["owner"] = args.owner
+    if args.owner_flush > 0:
+        eng.set_option("owner_flush", args.owner_flush); mode["owner_flush"] = args.owner_flush
+    if mode["group"] or mode["pos_share"] == 2 or args.overlap:
+        mode["owner"] = 0   # the engine falls back to the plain kernel in these modes
     eng.set_option("profile", 1)
     steps_per_epoch = eng.steps_per_epoch
     my_steps = steps_per_epoch // world
+    if my_steps < (1 << 20):
+        mode["owner"] = 0   # launches below "owner_min" are not partitioned
 
-    # item tables (replicated) as torch tensors over engine memory, for the all-reduce
-    item_tabs = []
-    if world > 1:
-        for ptr, rows, cols, is_user in eng.tables():
-            if not is_user:
-                t = torch.as_tensor(DevArray(ptr, (rows * cols,), "<f4" if prec == F32 else "<f8"), device=dev)
-                item_tabs.append((t, torch.empty_like(t)))
-
-    def barrier():
-        eng.sync()
+    def barrier(e=None):
+        (e or eng).sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def one_step(epoch):
-        for t, base in item_tabs:
-            base.copy_(t)
-        torch.cuda.synchronize()
-        eng.sgd_epoch(0.05, my_steps, seed=99, epoch=epoch * world + rank)
-        eng.sync()
-        if item_tabs:
-            combine_item_tables([t for t, _ in item_tabs], [b for _, b in item_tabs], world, lambda t: all_reduce(t, dist.ReduceOp.SUM))
-            torch.cuda.synchronize()
-
-    for w in range(args.warmup):
-        one_step(w)
-    barrier()
-    eng.kernel_stats(0); eng.kernel_stats(2)   # reset the HIP-event counters
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        one_step(args.warmup + s)
-    barrier()
-    dt = time.perf_counter() - t0
-    upd_ms, upd_n = eng.kernel_stats(0)
-    smp_ms, smp_n = eng.kernel_stats(2)
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        all_reduce(tt, dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    total_triples = my_steps * world * args.steps   # expected; the event-major sampler draws Poisson(this) tuples
-    value = total_triples / dt
-
-    # algorithmic bytes per triple: distinct rows read once + written once (model-specific)
+    # exact mean number of distinct history rows a REBUS step touches: |S| = distinct items of the prefix before the
+    # target position, averaged over the (user, position) pairs the sampler draws (user uniform, position uniform)
     mean_hist = float(seq_off[-1]) / U
-    rows = {"BPRMF": 3, "MC": 3, "HRM_avg": 4, "HRM_max": 4, "TransRec": 4, "TransRec_L1": 4, "FPMC": 6, "PRME": 6,
-            # history models: every item of the user's history (REBUS: about half of it, the distinct prefix) + pos + neg
-            "Fossil": mean_hist + 2, "FossilSimple": mean_hist + 2, "REBUS": mean_hist / 2 + 2}[args.model]
-    scalars = {"BPRMF": 2, "TransRec": 2, "TransRec_L1": 2, "Fossil": 2 + 2 * L, "FossilSimple": 4, "REBUS": 2}.get(args.model, 0)
-    bytes_per_triple = int(2 * rows * K * esz + 2 * scalars * esz)
-    tuples_per_launch = my_steps * args.steps / max(upd_n, 1)
-    avg_ms = upd_ms / max(upd_n, 1)
-    achieved = bytes_per_triple * tuples_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    # HBM traffic per launch from the committed rocprofv3 --pmc passes of this same command (profiles/pmc_summary.json);
-    # only quoted when the profiled launch had the same size
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
-    if os.path.exists(pmc_path) and args.model == "BPRMF" and world == 1:
-        for name, e in json.load(open(pmc_path)).items():
-            if name.startswith("sgd_runs_kernel" if grouped else "sgd_hogwild_kernel") and "hbm_traffic_bytes_per_launch" in e and \
-                    abs(e.get("tuples_per_launch", 0) - tuples_per_launch) < 0.01 * tuples_per_launch:
-                traffic = int(e["hbm_traffic_bytes_per_launch"])
-    roofline = {"bound": "hbm", "kernel": "sgd_history_batch_kernel" if args.model in ("Fossil", "FossilSimple", "REBUS") else "sgd_runs_kernel" if grouped else "sgd_hogwild_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "bytes_per_triple": bytes_per_triple, "tuples_per_launch": int(tuples_per_launch),
-                "avg_launch_ms": round(avg_ms, 4), "launches": int(upd_n),
-                "sampler_ms_per_launch": round(smp_ms / max(smp_n, 1), 4),
-                "tuples_drawn_over_expected": round(eng.tuples_drawn / max(1, my_steps * (args.steps + args.warmup)), 6)}
+    rebus_rows = None
+    if args.model == "REBUS":
+        lens = np.diff(seq_off)
+        elig = np.nonzero(lens >= 2)[0]
+        sample_u = elig[:: max(1, len(elig) // 20000)]
+        acc = 0.0
+        for u in sample_u:
+            seq = seq_item[seq_off[u]:seq_off[u + 1]]
+            seen, sizes = set(), []
+            for x in seq[:-1]:
+                seen.add(int(x)); sizes.append(len(seen))
+            acc += float(np.mean(sizes))   # target positions 1 .. n-1: prefix of 1 .. n-1 items
+        rebus_rows = acc / len(sample_u)
 
-    # what actually bounds the hybrid scatter: float atomics execute at the memory side at about 1.3 TB/s chip-wide
-    atomic_rows = {"BPRMF": 2, "MC": 3, "HRM_avg": 3, "HRM_max": 3, "TransRec": 3, "TransRec_L1": 3, "FPMC": 5, "PRME": 5}.get(args.model)
-    neg_rows = {"BPRMF": 1, "MC": 1, "HRM_avg": 1, "HRM_max": 1, "FPMC": 2, "PRME": 2}.get(args.model, 0)
-    if atomic_rows and policy == 1 and avg_ms > 0:
-        # a negative shared by two steps is scattered once for both
-        ab = int((atomic_rows - (neg_rows / 2 if (neg_share == 2 or pos_share == 2) else neg_rows * 3 / 4 if neg_share == 4 else 0)
-                  - (neg_rows / 2 if pos_share == 2 else 0)) * K * esz)   # a model has as many positive rows as negative ones
-        rate = ab * tuples_per_launch / (avg_ms * 1e-3) / 1e9
-        roofline["atomic"] = {"bytes_per_triple": ab, "achieved": round(rate, 1), "peak": 1300.0, "unit": "GB/s",
+    def measure(e, md, prec_name, steps, warmup, item_tabs=(), epoch0=0):
+        """steps timed SGD epochs on engine e -> the fields of one bench entry."""
+        esz_ = 4 if prec_name == "f32" else 8
+
+        def one_step(epoch):
+            for t, base in item_tabs:
+                base.copy_(t)
+            if item_tabs:
+                torch.cuda.synchronize()
+            e.sgd_epoch(0.05, my_steps, seed=99, epoch=epoch * world + rank)
+            e.sync()
+            if item_tabs:
+                combine_item_tables([t for t, _ in item_tabs], [b for _, b in item_tabs], world, lambda t: all_reduce(t, dist.ReduceOp.SUM))
+                torch.cuda.synchronize()
+
+        for w in range(warmup):
+            one_step(epoch0 + w)
+        barrier(e)
+        for which in (0, 2, 3):
+            e.kernel_stats(which)   # reset the HIP-event counters
+        t0 = time.perf_counter()
+        for s_ in range(steps):
+            one_step(epoch0 + warmup + s_)
+        barrier(e)
+        dt = time.perf_counter() - t0
+        upd_ms, upd_n = e.kernel_stats(0)
+        smp_ms, smp_n = e.kernel_stats(2)
+        part_ms, part_n = e.kernel_stats(3)
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            all_reduce(tt, dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        grouped = md["group"] == 2 and args.model in GROUP_MODELS
+        # algorithmic bytes per triple: every distinct row / scalar a step names, read once + written once.  Steps that
+        # share an item by construction (pairs drawing one negative, or one positive and one negative) name it once per pair.
+        rows = {"BPRMF": 3, "MC": 3, "HRM_avg": 4, "HRM_max": 4, "TransRec": 4, "TransRec_L1": 4, "FPMC": 6, "PRME": 6,
+                "Fossil": mean_hist + 2, "FossilSimple": mean_hist + 2, "REBUS": (rebus_rows or 0) + 2}[args.model]
+        scalars = {"BPRMF": 2, "TransRec": 2, "TransRec_L1": 2, "Fossil": 2 + 2 * L, "FossilSimple": 4, "REBUS": 2}.get(args.model, 0)
+        item_rows_per_role = {"FPMC": 2, "PRME": 2}.get(args.model, 1)
+        if args.model in GROUP_MODELS:
+            shared = 0.0
+            if md["neg_share"] > 1 or md["pos_share"] == 2:
+                shared += 1.0 - 1.0 / max(md["neg_share"], 2)
+            if md["pos_share"] == 2:
+                shared += 0.5
+            rows -= shared * item_rows_per_role
+            if args.model == "BPRMF":
+                scalars -= shared
+        bytes_per_triple = int(round(2 * rows * K * esz_ + 2 * scalars * esz_))
+        launches = max(upd_n, 1)
+        tuples_per_launch = my_steps * steps / launches
+        kern_ms = (upd_ms - part_ms) / launches          # the update kernel alone (owner mode: without its partition pass)
+        achieved = bytes_per_triple * tuples_per_launch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        kernel = "sgd_history_batch_kernel" if args.model in HISTORY_MODELS else "sgd_runs_kernel" if grouped else \
+            ("sgd_wide_kernel" if (prec_name == "f32" and K % 4 == 0 and K >= 8 and md["neg_share"] == 1 and md["pos_share"] == 1 and args.wide != 0) else "sgd_hogwild_kernel") + ("<OWNER>" if md["owner"] else "")
+        roof = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_triple": bytes_per_triple,
+                "tuples_per_launch": int(tuples_per_launch), "avg_launch_ms": round(kern_ms, 4), "launches": int(upd_n),
+                "sampler_ms_per_launch": round(smp_ms / max(smp_n, 1), 4),
+                "partition_ms_per_launch": round(part_ms / launches, 4)}
+        # what bounds the scatter: float atomics execute at the memory side at about 1.3 TB/s chip-wide
+        atomic_rows = {"BPRMF": 2, "MC": 3, "HRM_avg": 3, "HRM_max": 3, "TransRec": 3, "TransRec_L1": 3, "FPMC": 5, "PRME": 5}.get(args.model)
+        if atomic_rows and md["policy"] == 1 and kern_ms > 0:
+            neg_rows = item_rows_per_role
+            ar = float(atomic_rows)
+            if md["owner"]:
+                # negatives whose item has an LDS accumulator cost one atomic row per owner_flush additions
+                slice_rows = (I + 255) // 256
+                acc_w = K * (2 if args.model in ("FPMC", "PRME") else 1)
+                res = min(slice_rows, (160 * 1024 - 2048) // (acc_w * esz_ + 4))
+                frac_res = res / slice_rows
+                ar -= neg_rows * frac_res * (1.0 - 1.0 / md["owner_flush"])
+            elif args.model in GROUP_MODELS:
+                if md["neg_share"] > 1 or md["pos_share"] == 2:
+                    ar -= neg_rows * (1.0 - 1.0 / max(md["neg_share"], 2))
+                if md["pos_share"] == 2:
+                    ar -= neg_rows * 0.5
+            ab = int(round(ar * K * esz_))
+            rate = ab * tuples_per_launch / (kern_ms * 1e-3) / 1e9
+            roof["atomic"] = {"bytes_per_triple": ab, "achieved": round(rate, 1), "peak": 1300.0, "unit": "GB/s",
                               "frac": round(rate / 1300.0, 4)}
+        update = ["float atomics on every row", "float atomics on item rows (plain stores for user rows, biases and items holding >= 1/1024 of the positives)", "plain stores"][md["policy"]]
+        if grouped:
+            update += ", chunks drawn by event and grouped by positive item, one atomic row per run"
+        if md["owner"]:
+            update += f"; launch partitioned by the negative's slice of the catalog, negatives' deltas summed in LDS, one atomic row per {md['owner_flush']} additions"
+        if md["pos_share"] == 2 and md["policy"] != 2:
+            update += "; pairs of steps share their positive and their negative, each scattered once for both"
+        elif md["neg_share"] >= 2 and md["policy"] != 2:
+            update += f"; groups of {md['neg_share']} steps share their negative, scattered once for all"
+        else:
+            update += "; every step draws its own negative (the reference's sampling)"
+        total_triples = my_steps * world * steps   # expected; the event-major sampler draws Poisson(this) tuples
+        return {"value": round(total_triples / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3), "dtype": prec_name,
+                "update": update, "roofline": roof}
+
+    # item tables (replicated) as torch tensors over engine memory, for the all-reduce
+    item_tabs = []
+    if world > 1:
+        for ptr, rows_, cols, is_user in eng.tables():
+            if not is_user:
+                t = torch.as_tensor(DevArray(ptr, (rows_ * cols,), "<f4" if prec == F32 else "<f8"), device=dev)
+                item_tabs.append((t, torch.empty_like(t)))
+
+    main_res = measure(eng, mode, args.precision, args.steps, args.warmup, item_tabs)
+    roofline = main_res["roofline"]
+    roofline["tuples_drawn_over_expected"] = round(eng.tuples_drawn / max(1, my_steps * (args.steps + args.warmup)), 6)
     # practical ceiling: a device-to-device copy of 1 GiB (read + write counted)
     src = torch.empty(1 << 28, dtype=torch.float32, device=dev); dst = torch.empty_like(src)
     dst.copy_(src); torch.cuda.synchronize()
@@ -327,15 +436,43 @@ def main():
     torch.cuda.synchronize()
     roofline["measured_copy_gbs"] = round(5 * 2 * src.numel() * 4 / (time.perf_counter() - c0) / 1e9, 1)
     del src, dst
+    value = main_res["value"]
 
-    out = {"metric": "bpr_sgd_triples_per_sec", "value": round(value, 1), "unit": "triples/s", "n_gpus": world,
-           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+    out = {"metric": "bpr_sgd_triples_per_sec", "value": value, "unit": "triples/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.precision,
            "data": "synthetic",
            "config": {"workload": f"{args.model} K={K} oneiteration (BPR-SGD epoch) on synthetic {U} users x {I} items x "
                                   f"{n_clicks} interactions", "triples_per_step": my_steps * world,
-                      "update": ["float atomics on every row", "float atomics on item rows (plain stores for user rows, biases and items holding >= 1/1024 of the positives)", "plain stores"][policy] + (", chunks drawn by event and grouped by positive item, one atomic row per run" if grouped else "") + ("; pairs of steps share their positive and their negative, each scattered once for both" if pos_share == 2 and policy != 2 else "; pairs of steps share their negative, scattered once for both" if neg_share == 2 and policy != 2 else ""), "parallelism": f"user-sharded x{world}"},
+                      "update": main_res["update"], "parallelism": f"user-sharded x{world}"},
            "roofline": roofline}
+
+    # ---------------- the other scatter modes and f64 storage, same corpus, same measurement (N=1 only)
+    if world == 1 and not args.no_variants and args.model in GROUP_MODELS and args.policy < 0 and args.owner < 0 and \
+            args.share_negative == 0 and args.share_positive == 0 and args.group < 0:
+        variants = {}
+        vsteps = max(2, min(args.steps, 3))
+
+        def variant(name, opts, md):
+            for k, v in opts.items():
+                eng.set_option(k, v)
+            r = measure(eng, md, args.precision, vsteps, 1, epoch0=1000 * (len(variants) + 1))
+            variants[name] = {"triples_per_sec": r["value"], "ms_per_step": r["ms_per_step"], "update": r["update"], "roofline": r["roofline"]}
+
+        if mode["owner"]:
+            variant("atomics_per_tuple", {"owner_neg": 0}, dict(mode, owner=0))
+            variant("pairs_share_negative", {"owner_neg": 0, "share_negative": 2}, dict(mode, owner=0, neg_share=2))
+            variant("plain_stores", {"share_negative": 1, "update_policy": 2}, dict(mode, owner=0, policy=2))
+            eng.set_option("update_policy", mode["policy"]); eng.set_option("owner_neg", 1)
+        if args.precision == "f32":
+            e64 = ra.Engine(args.model, I, seq_off, seq_item, test_item, val_item, K=K, L=L, lam=0.01, bias_reg=0.01,
+                            relation_reg=0.01, alpha=0.5, precision=F64, device=local_rank, user_begin=ub, user_end=ue)
+            e64.init_params(seed=2024)
+            e64.set_option("chunk", args.chunk); e64.set_option("profile", 1)
+            r = measure(e64, mode, "f64", vsteps, 1)
+            variants["f64_storage"] = {"triples_per_sec": r["value"], "ms_per_step": r["ms_per_step"], "update": r["update"], "roofline": r["roofline"]}
+            e64.close()
+        out["variants"] = variants
 
     # ---------------- evaluation: users/s over the full catalog
     if not args.no_eval:
@@ -399,7 +536,11 @@ def main():
         ct = time.perf_counter() - t0
         out["eval"]["cpu_baseline"] = {"value": round(len(sample) / ct, 2), "unit": "users/s", "cores": cores, "kind": "port",
                                        "sample": f"{len(sample)} evenly spaced users, full catalog, fp64, {ct:.1f} s"}
-        out["eval"]["gpu_over_cpu"] = round(out["eval"]["users_per_sec"] / (len(sample) / ct), 1)
+        out["eval"]["cpu_port"] = out["eval"]["cpu_baseline"]
+        ref = _time_reference_eval(args, seq_off, seq_item, test_item, val_item, K, I)
+        if ref is not None:
+            out["eval"]["cpu_baseline"] = ref
+        out["eval"]["gpu_over_cpu"] = round(out["eval"]["users_per_sec"] / out["eval"]["cpu_baseline"]["value"], 1)
 
     if rank == 0:
         print(json.dumps(out), flush=True)

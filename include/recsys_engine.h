@@ -127,6 +127,11 @@ int rec_sample_events(rec_engine* e, int64_t n_expected, uint64_t seed, uint64_t
 /* the sampler alone (tests, tuple capture): writes n tuples (4 x int32) to host memory */
 int rec_sample_tuples(rec_engine* e, int64_t n, uint64_t seed, uint64_t epoch, int32_t* tuples_out);
 
+/* No counterpart in the reference: the partition step of the update's owner mode ("owner_neg") alone, for inspection.
+ * The n tuples ordered by the slice of the catalog their negative item lies in (256 slices of ceil(n_items / 256)
+ * consecutive items): out receives the tuples, qoff_out[0..256] where each slice starts in it. */
+int rec_partition_tuples(rec_engine* e, const int32_t* tuples, int64_t n, int32_t* out, int64_t* qoff_out);
+
 /* number of updateFactors calls per epoch: num_pos_events (src/model.hpp:47-51), MC: num_pos_trans (MC.cpp:19-22) */
 int64_t rec_steps_per_epoch(const rec_engine* e);
 
@@ -176,6 +181,17 @@ int rec_num_tables(const rec_engine* e);
 int rec_table_info(const rec_engine* e, int t, void** dev_ptr, int64_t* rows, int64_t* cols, int* is_user_table);
 
 /* Tuning knobs (value 0/1 unless noted):
+ *   "owner_neg"     BPRMF / MC / FPMC / PRME / HRM / TransRec: 1 = a launch of at least "owner_min" tuples is first
+ *                   partitioned by the slice of the catalog its negative items lie in, and workgroup s of the update
+ *                   applies slice s, summing the negatives' deltas in LDS and moving a row's sum to memory with one
+ *                   atomic row per "owner_flush" additions (default 8) instead of one per tuple.  Every tuple keeps the
+ *                   reference's sampling (independent negatives).  Default 1 where "share_negative" 2 used to be:
+ *                   epochs of >= 4M steps, not TransRec.
+ *   "owner_flush", "owner_min"   see above (defaults 8 and 2^20)
+ *   "wide"          1 (default) = f32 tables with K and KK multiples of 4 are updated by the form of the Hogwild kernel that
+ *                   holds four consecutive components per lane (16-byte row accesses, four tuples per wave-instruction at
+ *                   K = 64); 0 = always the one-dword-per-lane form (which also serves every other K, f64 and the shared
+ *                   negatives / positives)
  *   "update_policy" 0 = float atomics on every row, 1 = hybrid (plain stores for user rows, biases and the few
  *                   items drawn most often, atomics on the other item rows), 2 = plain racy stores
  *   "atomic"        the same as a bit mask: bit r = row r of the tuple, bit 8 = biases
@@ -209,8 +225,8 @@ int rec_table_info(const rec_engine* e, int t, void** dev_ptr, int64_t* rows, in
  *   "profile"       time every update / scoring / sampler launch with HIP events */
 int rec_set_option(rec_engine* e, const char* name, int64_t value);
 
-/* HIP-event statistics gathered while "profile" = 1: which = 0 SGD update kernel, 1 eval scoring
- * kernel, 2 sampler.  Resets the counters. */
+/* HIP-event statistics gathered while "profile" = 1: which = 0 SGD update (in owner mode: the partition and the update
+ * kernel together), 1 eval scoring kernel, 2 sampler, 3 the owner mode's partition alone.  Resets the counters. */
 int rec_kernel_stats(rec_engine* e, int which, double* total_ms, int64_t* launches);
 
 #ifdef __cplusplus

@@ -28,7 +28,7 @@ RUNS = [
     ("REBUS", 3, 2, 0.01, 0.0, 0.0, -0.6, 40, 4),
     ("FossilSimple", 1, 1, 0.01, 0.01, 0.0, 0.0, 40, 4),
 ]
-SEEDS = (0, 1, 2)
+SEEDS = (0, 2, 3)   # glibc treats srand(0) as srand(1): seed 1 would repeat seed 0
 
 
 def run(job):

@@ -160,7 +160,8 @@ static void finish_simple(M& md)
 
 // "traj:N:C" in place of the tuples file: N epochs of the model's own oneiteration()/oneIteration(),
 // the model's own AUC() every C epochs; prints "EPOCH iter seconds" after every epoch and
-// "TRAJ iter AUC_val AUC_test HIT_val HIT_test" after every evaluation.
+// "TRAJ iter AUC_val AUC_test HIT_val HIT_test" and "EVALSEC iter seconds" (the time of that AUC() call) after every
+// evaluation.
 static int g_traj_n = 0, g_traj_c = 0;
 #define TRAJ(md, EPOCH_CALL)                                                                  \
 	do {                                                                                      \
@@ -170,8 +171,11 @@ static int g_traj_n = 0, g_traj_c = 0;
 			fprintf(stderr, "EPOCH %d %.6f\n", it,                                            \
 			        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count()); \
 			if (it % g_traj_c == 0) {                                                         \
+				const auto e0_ = std::chrono::steady_clock::now();                            \
 				double m[7]; md.AUC(&m[0], &m[1], &m[2], &m[3], &m[4], &m[5], &m[6]);         \
 				fprintf(stderr, "TRAJ %d %.6f %.6f %.6f %.6f\n", it, m[0], m[1], m[2], m[3]);  \
+				fprintf(stderr, "EVALSEC %d %.6f\n", it,                                      \
+				        std::chrono::duration<double>(std::chrono::steady_clock::now() - e0_).count()); \
 			}                                                                                 \
 		}                                                                                     \
 	} while (0)

@@ -78,6 +78,24 @@ void rec_set_error(const std::string& msg);
 int launch_sgd_sequential(const DevModel& m, int precision, const int4* tuples, int64_t n, double lr, hipStream_t st);
 int launch_sgd_hogwild(const DevModel& m, int precision, const int4* tuples, int64_t n, double lr, int atomic,
                        hipStream_t st);
+// Owner mode of the Hogwild kernel: `partitioned` holds the launch's tuples ordered by the slice of the catalog their
+// negative item lies in (launch_partition_by_slice), qoff[s] .. qoff[s+1] being slice s; workgroup s applies them and
+// keeps the negatives' deltas in LDS accumulators, moved to memory once per flush_at additions.
+bool sgd_owner_supported(int model);
+int sgd_owner_slices();
+int sgd_owner_slice_rows(const DevModel& m);
+int sgd_owner_neg_field(int model);   // component of the tuple that holds the negative item (2 = z, 3 = w)
+int launch_sgd_owner(const DevModel& m, int precision, const int4* partitioned, const int64_t* qoff, int64_t n, double lr, int atomic,
+                     int flush_at, hipStream_t st);
+// The wide form of the Hogwild kernel (sgd_wide.hip): f32 tables, K and KK multiples of 4; qoff as for launch_sgd_owner
+// (nullptr: plain mode on the tuples as they come)
+bool sgd_wide_supported(const DevModel& m, int precision);
+int launch_sgd_wide(const DevModel& m, const int4* tuples, const int64_t* qoff, int64_t n, double lr, int atomic, int flush_at, hipStream_t st);
+// Stable-by-block partition of n tuples by (component `field`) / slice_rows into `slices` ranges of dst; qoff[slices+1]
+// (device) receives the range starts.  scratch: partition_scratch_bytes(n, slices).
+size_t partition_scratch_bytes(int64_t n, int slices);
+int launch_partition_by_slice(const int4* src, int4* dst, int64_t n, int field, int slice_rows, int slices, void* scratch,
+                              int64_t* qoff, hipStream_t st);
 int launch_apply_global(const DevModel& m, int precision, double lr, int64_t n_tuples, double cap, hipStream_t st);
 // max_in_flight: upper bound on the tuples being worked on at the same time (0 = as many as the chip holds).
 // batch (1, 2, 4, 8): the tuples come in aligned groups of `batch` consecutive tuples of one user; one wavefront
@@ -138,7 +156,36 @@ __device__ __forceinline__ double rsqrt_(double x) { return sqrt(x); }
 __device__ __forceinline__ float rabs(float x) { return fabsf(x); }
 __device__ __forceinline__ double rabs(double x) { return fabs(x); }
 
-// sum over the lanes of an aligned group of W lanes (W = 16, 32 or 64); every lane gets the sum
+// value of the lane a DPP control selects inside each row of 16 lanes: quad_perm [1,0,3,2] = 0xB1 (lane ^ 1),
+// quad_perm [2,3,0,1] = 0x4E (lane ^ 2), row_half_mirror = 0x141 (7 - lane inside 8), row_mirror = 0x140 (15 - lane)
+template <int CTRL> __device__ __forceinline__ float dpp_move(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_move(double x)
+{
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// sum over the lanes of an aligned group of W lanes (W = 2 .. 64); every lane gets the sum.  Inside a row of 16 lanes
+// the partners are reached by DPP modifiers of the additions themselves (no LDS crossbar, no wait): after the steps
+// lane ^ 1 and lane ^ 2 a quad is uniform, so mirroring inside 8 and inside 16 lanes reaches the other half each time.
+template <int W, class T>
+__device__ __forceinline__ T group_sum_dpp(T v)
+{
+    if constexpr (W >= 2) v += dpp_move<0xB1>(v);
+    if constexpr (W >= 4) v += dpp_move<0x4E>(v);
+    if constexpr (W >= 8) v += dpp_move<0x141>(v);
+    if constexpr (W >= 16) v += dpp_move<0x140>(v);
+    if constexpr (W >= 32) v += __shfl_xor(v, 16, 64);
+    if constexpr (W >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// the same through the LDS crossbar alone (ds_bpermute), highest distance first
 template <int W, class T>
 __device__ __forceinline__ T group_sum(T v)
 {

@@ -53,8 +53,14 @@ struct rec_engine {
     int pos_share = 1;   // 2: steps 2p, 2p+1 of an epoch also share their positive item (launch_pair_sampler)
     int neg_share = 1;   // consecutive steps of an epoch that share their stream of negative candidates (group models)
     int user_batch = 1;  // consecutive steps of an epoch that share their user draw (history models)
+    int wide = 1;        // 1: the wide form of the Hogwild kernel (sgd_wide.hip) where it applies
+    int owner = 0;       // 1: launches of >= owner_min tuples are partitioned by the negative's slice of the catalog and applied in owner mode
+    int owner_flush = 8; // additions after which an LDS accumulator row is moved to memory
+    int64_t owner_min = 1 << 20;
+    void* part_scratch = nullptr; size_t part_scratch_bytes = 0;
+    int64_t* qoff_dev = nullptr;
     int group = 0;       // 1: run-combining update kernel on the tuples as they come; 2: also sample by event, which yields chunks grouped by positive item
-    // hip-event statistics: 0 update, 1 score, 2 sampler, 3 unused
+    // hip-event statistics: 0 update (owner mode: partition + update kernel), 1 score, 2 sampler, 3 the owner mode's partition
     double ms[4] = {0, 0, 0, 0};
     int64_t launches[4] = {0, 0, 0, 0};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[4];
@@ -338,12 +344,14 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     // pairs are only the default where histories are long; "user_batch" sets it either way.
     const double mean_history = U > 0 ? (double)E / (double)U : 0.0;
     e->user_batch = (history_model(d->model) && e->steps_per_epoch >= (1 << 22) && mean_history >= 16.0) ? 2 : 1;
-    // The other models draw the negatives of two consecutive steps from one candidate stream (sampler.hip), and the update
-    // kernel scatters the shared negative's rows once for both.  Measured on the same corpus: 1.2-1.3x the throughput;
-    // early-stopped test AUC after 15-20 epochs lower by 0.0002 (FPMC, TransRec) to 0.0018 (HRM_avg), BPRMF 0.0008.
-    // "share_negative" 1 restores independent candidate streams.
-    const bool transrec = d->model == REC_TRANSREC || d->model == REC_TRANSREC_L1;   // bound by its arithmetic: nothing to gain
-    e->neg_share = (!history_model(d->model) && !transrec && e->steps_per_epoch >= (1 << 22)) ? 2 : 1;
+    // The other models: launches of a large epoch run in owner mode (sgd_hogwild.hip) - partitioned by the negative's
+    // slice of the catalog, the negatives' deltas summed in LDS - which removes most of the float atomics the
+    // negatives cost while every step keeps the reference's independent negative.  Not TransRec, whose step is bound
+    // by the arithmetic of its projections.  ("share_negative" 2, pairs of steps drawing one negative, is the older
+    // way to the same saving; it changes the joint distribution of consecutive steps and stays an option.)
+    const bool transrec = d->model == REC_TRANSREC || d->model == REC_TRANSREC_L1;
+    e->owner = (!history_model(d->model) && !transrec && sgd_owner_supported(d->model) && e->steps_per_epoch >= (1 << 22)) ? 1 : 0;
+    e->neg_share = 1;
     *out = e;
     return 0;
 }
@@ -356,12 +364,14 @@ extern "C" int rec_destroy(rec_engine* e)
     if (e->st2) (void)hipStreamSynchronize(e->st2);
     for (int b = 0; b < 2; b++) { if (e->ev_sampled[b]) (void)hipEventDestroy(e->ev_sampled[b]); if (e->ev_consumed[b]) (void)hipEventDestroy(e->ev_consumed[b]); }
     if (e->st2) (void)hipStreamDestroy(e->st2);
-    for (int w = 0; w < 3; w++) for (auto& p : e->pending[w]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (int w = 0; w < 4; w++) for (auto& p : e->pending[w]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (void* p : e->owned) (void)hipFree(p);
     if (e->W) (void)hipFree(e->W);
     if (e->bestW) (void)hipFree(e->bestW);
     if (e->stage) (void)hipFree(e->stage);
     if (e->tuples) (void)hipFree(e->tuples);
+    if (e->part_scratch) (void)hipFree(e->part_scratch);
+    if (e->qoff_dev) (void)hipFree(e->qoff_dev);
     if (e->st) (void)hipStreamDestroy(e->st);
     delete e;
     return 0;
@@ -573,6 +583,21 @@ static int ensure_events(rec_engine* e)
     return 0;
 }
 
+static int ensure_partition_scratch(rec_engine* e, int64_t n)
+{
+    const int slices = sgd_owner_slices();
+    const size_t need = partition_scratch_bytes(n, slices);
+    if (e->part_scratch_bytes < need) {
+        ENG_HIP(hipStreamSynchronize(e->st));
+        if (e->part_scratch) (void)hipFree(e->part_scratch);
+        e->part_scratch = nullptr; e->part_scratch_bytes = 0;
+        ENG_HIP(hipMalloc(&e->part_scratch, need));
+        e->part_scratch_bytes = need;
+    }
+    if (!e->qoff_dev) { ENG_HIP(hipMalloc((void**)&e->qoff_dev, sizeof(int64_t) * (slices + 8))); }
+    return 0;
+}
+
 // Hogwild launches over `n` tuples.  Models with a row that every tuple touches (TransRec's r,
 // Fossil's WT, FossilSimple's alpha) keep that row constant during a launch and fold its summed
 // gradient in afterwards, so their launches are kept short (`global_window` tuples).
@@ -590,8 +615,30 @@ static int launch_update(rec_engine* e, const int4* tuples, int64_t n, double lr
     if (window < n && (user_batch > 1 || e->neg_share > 1 || e->pos_share > 1) && window > 8) window &= ~(int64_t)7;   // launches start on a group boundary
     for (int64_t o = 0; o < n; o += window) {
         const int64_t len = std::min(window, n - o);
+        // owner mode: needs room for the partitioned copy, which is the second half of the engine's tuple buffer
+        const bool use_wide = e->wide && !history && e->neg_share == 1 && e->pos_share == 1 && sgd_wide_supported(e->dm, e->desc.precision);
+        const bool in_own_buffer = e->tuples && tuples + o >= e->tuples && tuples + o + len <= e->tuples + e->tuples_cap;
+        if (e->owner && !history && !grouped && e->group == 0 && !e->overlap && in_own_buffer && len >= e->owner_min &&
+            sgd_owner_supported(model)) {
+            const int slices = sgd_owner_slices();
+            if (int rc = ensure_partition_scratch(e, len)) return rc;
+            int4* dst = (int4*)(tuples + o) + e->tuples_cap;
+            hipEvent_t pa = nullptr, pb = nullptr;
+            if (e->profile) { ENG_HIP(hipEventCreate(&pa)); ENG_HIP(hipEventCreate(&pb)); ENG_HIP(hipEventRecord(pa, e->st)); }
+            int rc = launch_partition_by_slice(tuples + o, dst, len, sgd_owner_neg_field(model), sgd_owner_slice_rows(e->dm), slices,
+                                               e->part_scratch, e->qoff_dev, e->st);
+            if (e->profile) { ENG_HIP(hipEventRecord(pb, e->st)); e->pending[3].push_back({pa, pb}); }
+            if (!rc) rc = use_wide ? launch_sgd_wide(e->dm, dst, e->qoff_dev, len, lr, e->atomic, e->owner_flush, e->st)
+                                   : launch_sgd_owner(e->dm, e->desc.precision, dst, e->qoff_dev, len, lr, e->atomic, e->owner_flush, e->st);
+            if (rc) return rc;
+            if (global_row) {
+                if ((rc = launch_apply_global(e->dm, e->desc.precision, lr, len, (double)e->global_cap, e->st))) return rc;
+            }
+            continue;
+        }
         int rc = history ? launch_sgd_history(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic, e->stale_window, user_batch, e->st)
                  : ((grouped || e->group == 1) && sgd_runs_supported(model)) ? launch_sgd_runs(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic, e->run_segment, e->run_policy, e->st)
+                 : use_wide ? launch_sgd_wide(e->dm, tuples + o, nullptr, len, lr, e->atomic, 1, e->st)
                          : launch_sgd_hogwild(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic | ((e->neg_share >= 4 ? 2 : (e->neg_share == 2 || e->pos_share == 2) ? 1 : 0) << 16), e->st);
         if (rc) return rc;
         if (global_row) {
@@ -774,6 +821,25 @@ extern "C" int rec_sample_events(rec_engine* e, int64_t n_expected, uint64_t see
     return 0;
 }
 
+extern "C" int rec_partition_tuples(rec_engine* e, const int32_t* tuples, int64_t n, int32_t* out, int64_t* qoff_out)
+{
+    if (!e || !tuples || !out || !qoff_out) { rec_set_error("null argument"); return -1; }
+    if (!sgd_owner_supported(e->desc.model)) { rec_set_error("the owner mode is not available for this model"); return -1; }
+    if (n <= 0) return 0;
+    ENG_HIP(hipSetDevice(e->desc.device));
+    if (int rc = check_tuples(e, tuples, n)) return rc;
+    if (int rc = ensure_tuples(e, n)) return rc;
+    if (int rc = ensure_partition_scratch(e, n)) return rc;
+    const int slices = sgd_owner_slices();
+    ENG_HIP(hipMemcpyAsync(e->tuples, tuples, sizeof(int4) * n, hipMemcpyHostToDevice, e->st));
+    if (int rc = launch_partition_by_slice(e->tuples, e->tuples + e->tuples_cap, n, sgd_owner_neg_field(e->desc.model), sgd_owner_slice_rows(e->dm),
+                                           slices, e->part_scratch, e->qoff_dev, e->st)) return rc;
+    ENG_HIP(hipMemcpyAsync(out, e->tuples + e->tuples_cap, sizeof(int4) * n, hipMemcpyDeviceToHost, e->st));
+    ENG_HIP(hipMemcpyAsync(qoff_out, e->qoff_dev, sizeof(int64_t) * (slices + 1), hipMemcpyDeviceToHost, e->st));
+    ENG_HIP(hipStreamSynchronize(e->st));
+    return 0;
+}
+
 extern "C" int rec_sample_tuples(rec_engine* e, int64_t n, uint64_t seed, uint64_t epoch, int32_t* out)
 {
     if (!e || !out) { rec_set_error("null argument"); return -1; }
@@ -939,6 +1005,10 @@ extern "C" int rec_set_option(rec_engine* e, const char* name, int64_t value)
     }
     else if (s == "share_negative") { if (value != 1 && value != 2 && value != 4) { rec_set_error("share_negative must be 1, 2 or 4"); return -1; } e->neg_share = (int)value; }
     else if (s == "user_batch") { if (value != 1 && value != 2 && value != 4 && value != 8) { rec_set_error("user_batch must be 1, 2, 4 or 8"); return -1; } e->user_batch = (int)value; }
+    else if (s == "wide") { if (value != 0 && value != 1) { rec_set_error("wide must be 0 or 1"); return -1; } e->wide = (int)value; }
+    else if (s == "owner_neg") { if (value != 0 && value != 1) { rec_set_error("owner_neg must be 0 or 1"); return -1; } e->owner = (int)value; }
+    else if (s == "owner_flush") { if (value < 1 || value > 65536) { rec_set_error("owner_flush must be in 1..65536"); return -1; } e->owner_flush = (int)value; }
+    else if (s == "owner_min") { if (value < 1) { rec_set_error("owner_min must be positive"); return -1; } e->owner_min = value; }
     else if (s == "run_segment") { if (value < 0) { rec_set_error("run_segment must be >= 0"); return -1; } e->run_segment = value; }
     else if (s == "group_by_item") { if (value < 0 || value > 3) { rec_set_error("group_by_item must be 0..3"); return -1; } e->group = (int)value; }
     else if (s == "hot_count") {

@@ -14,20 +14,56 @@
 // Rows that every tuple touches (TransRec's r) are not scattered per tuple: their gradients are
 // summed per thread, per block through LDS, and land in DevModel::gacc with one atomic per block;
 // launch_apply_global folds them into the row after the launch.
+//
+// Owner mode (template parameter OWNER).  Float atomics execute at the memory side at a fixed chip-wide byte rate,
+// far below the rate of loads and plain stores, so a scatter that adds two item rows per tuple is bound by them.  The
+// negative item of a tuple is uniform over the catalog, so the tuples of a launch are first partitioned by the
+// negative's slice of the catalog (partition.hip: 256 slices of consecutive items, equally loaded whatever the
+// popularity of the items), and workgroup b applies the tuples of slice b.  It keeps an f32 accumulator row in LDS for
+// the first `rows_res` items of its slice (as many as 160 KB hold): the negative's delta is added there
+// (ds_add_f32) instead of in memory, and a row's accumulated delta is moved to memory with ONE atomic row per
+// `flush_at` additions (and at the end of the launch).  Only this workgroup touches the item in the negative's role,
+// and it reads the row as memory + pending accumulator, so its own steps on an item see each other exactly; other
+// readers (the item as somebody's positive) see its negative updates at most flush_at - 1 steps late.  Items of the
+// slice beyond rows_res, and every other row, are scattered as in the plain mode.
 #include "common.h"
 #include "sgd_step.h"
+#include <algorithm>
 
-// ------------------------------------------------------------------------------------------------
-template <int MODEL, class T, int LPT, int EPL, int B>
-__global__ void __launch_bounds__(256) sgd_hogwild_kernel(DevModel m, const int4* __restrict__ tuples, int64_t n, T lr,
-                                                         int atomic)
+constexpr int OWNER_THREADS = 768;   // 12 waves: what the registers of this kernel allow a CU to hold
+
+template <int MODEL, class T, int LPT, int EPL, int B, bool OWNER>
+__global__ void __launch_bounds__(OWNER ? OWNER_THREADS : 256) sgd_hogwild_kernel(DevModel m, const int4* __restrict__ tuples, int64_t n, T lr,
+                                                                                 int atomic, OwnerArgs ow)
 {
     constexpr int R = Spec<MODEL>::R, NB = Spec<MODEL>::NB;
     constexpr bool TR = MODEL == REC_TRANSREC || MODEL == REC_TRANSREC_L1;
     const int g = threadIdx.x & (LPT - 1);
-    const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x / LPT);
-    const int64_t gid = (int64_t)blockIdx.x * (blockDim.x / LPT) + threadIdx.x / LPT;
+    // plain mode: the groups of all blocks stride over the batches of the launch; owner mode: the groups of block b
+    // stride over the batches of slice b
+    extern __shared__ __align__(16) unsigned char owner_lds[];
+    T* acc = (T*)owner_lds;                                                        // [rows_res][acc_width]
+    unsigned* pend = (unsigned*)(owner_lds + (size_t)ow.rows_res * ow.acc_width * sizeof(T));   // [rows_res] additions since the last flush
+    const int slice_base = OWNER ? (int)blockIdx.x * ow.slice_rows : 0;
+#ifdef OWNER_STAMPS
+    const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if constexpr (OWNER) {
+        const int64_t q0 = ow.qoff[blockIdx.x];
+        tuples += q0; n = ow.qoff[blockIdx.x + 1] - q0;
+        for (int i = threadIdx.x; i < ow.rows_res * ow.acc_width; i += blockDim.x) acc[i] = 0;
+        for (int i = threadIdx.x; i < ow.rows_res; i += blockDim.x) pend[i] = 0;
+        __syncthreads();
+    }
+    const int64_t ngroups = OWNER ? (int64_t)(blockDim.x / LPT) : (int64_t)gridDim.x * (blockDim.x / LPT);
+    const int64_t gid = OWNER ? (int64_t)(threadIdx.x / LPT) : (int64_t)blockIdx.x * (blockDim.x / LPT) + threadIdx.x / LPT;
     const int64_t nbatch = (n + B - 1) / B;
+    // accumulator slot of a tuple's negative item (-1: not resident here)
+    auto slot_of = [&](const int4& t) -> int {
+        if constexpr (!OWNER) return -1;
+        const int s = neg_item<MODEL>(t) - slice_base;
+        return (t.x >= 0 && s >= 0 && s < ow.rows_res) ? s : -1;
+    };
 
     T racc[EPL], rg[EPL];
 #pragma unroll
@@ -90,16 +126,58 @@ __global__ void __launch_bounds__(256) sgd_hogwild_kernel(DevModel m, const int4
     int4 tp[B], tn[B];
     T v[B][R][EPL], bs;
     int hf; uint8_t bias_hot;
-    load_idx(gid, tp);
-    load_idx(gid + ngroups, tn);
+    // Batches are claimed, not assigned by stride: lane groups advance at different speeds (their rows come from
+    // different places, their CU shares its memory path with others), and with an equal share each the launch ends
+    // with its slowest group.  Owner mode: one batch per claim from a counter in LDS; plain mode: CLAIM batches per
+    // claim from a counter in memory (one returning atomic per 256 tuples).
+    constexpr int CLAIM = OWNER ? 1 : 64;
+    __shared__ int lds_next;
+    if constexpr (OWNER) {
+        if (threadIdx.x == 0) lds_next = 0;
+        __syncthreads();
+    }
+    int64_t claim_cur = 0; int claim_left = 0;
+    auto next_batch = [&]() -> int64_t {
+        if (claim_left == 0) {
+            int c = 0;
+            if (g == 0) c = OWNER ? atomicAdd(&lds_next, CLAIM) : atomicAdd(m.work_counter, CLAIM);
+            claim_cur = __shfl(c, 0, LPT); claim_left = CLAIM;
+        }
+        claim_left--;
+        return claim_cur++;
+    };
+    // the batch being applied, and the two behind it in the pipeline (claims only grow, so once one of them lies past
+    // the end all later ones do)
+    int64_t b_p = next_batch(), b_n = next_batch();
+    load_idx(b_p, tp);
+    load_idx(b_n, tn);
     load_rows(tp, v, bs, hf, bias_hot);
-    for (int64_t batch = gid; batch < nbatch; batch += ngroups) {
+    while (b_p < nbatch) {
         // indices two batches ahead, rows one batch ahead
         int4 tnn[B];
-        load_idx(batch + 2 * ngroups, tnn);
+        const int64_t b_nn = next_batch();
+        load_idx(b_nn, tnn);
         T vn[B][R][EPL], bn;
         int hfn; uint8_t bias_hot_n;
         load_rows(tn, vn, bn, hfn, bias_hot_n);
+        if constexpr (OWNER) {
+            // an item's value as this workgroup knows it: memory + what it has added since the last flush.  Read here,
+            // when the batch is about to be used (its rows have been in flight for a whole iteration), not where the rows
+            // are requested: there the addition would make the wavefront wait for the rows it has just asked for.
+#pragma unroll
+            for (int b = 0; b < B; b++) {
+                const int sl = slot_of(tp[b]);
+                if (sl < 0) continue;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    if (!owned_row<MODEL>(r)) continue;
+                    const int width = (MODEL == REC_FPMC || MODEL == REC_PRME) && r == 5 ? m.KK : m.K;
+                    const T* a = acc + (size_t)sl * ow.acc_width + owned_off<MODEL>(r, m.K);
+#pragma unroll
+                    for (int j = 0; j < EPL; j++) { const int k = g + LPT * j; if (k < width) v[b][r][j] += a[k]; }
+                }
+            }
+        }
         // keep the values the plain-store mode adds its deltas to
         T old[B][R][EPL]; T mine = 0;  // mine: deri of the tuple whose bias this lane holds
         bool at[B][R];
@@ -160,12 +238,37 @@ __global__ void __launch_bounds__(256) sgd_hogwild_kernel(DevModel m, const int4
 #pragma unroll
         for (int b = 0; b < B; b++) {
             if (tp[b].x < 0) continue;
+            const int sl = slot_of(tp[b]);
+            bool accumulated = false;
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 if (folded[b][r]) continue;
                 int width; T* row = row_ptr<MODEL, T>(m, tp[b], r, width);
+                if (OWNER && owned_row<MODEL>(r) && sl >= 0 && at[b][r]) {
+                    T* a = acc + (size_t)sl * ow.acc_width + owned_off<MODEL>(r, m.K);
+#pragma unroll
+                    for (int j = 0; j < EPL; j++) { const int k = g + LPT * j; if (k < width) unsafeAtomicAdd(a + k, v[b][r][j]); }
+                    accumulated = true;
+                    continue;
+                }
 #pragma unroll
                 for (int j = 0; j < EPL; j++) { const int k = g + LPT * j; if (k < width) scatter(row + k, v[b][r][j], old[b][r][j], at[b][r]); }
+            }
+            if constexpr (OWNER) {
+                // every flush_at-th addition to an item moves its accumulated delta to memory: one atomic row for all of them
+                unsigned before = 0;
+                if (accumulated && g == 0) before = atomicInc(pend + sl, (unsigned)(ow.flush_at - 1));
+                before = __shfl(before, 0, LPT);
+                if (accumulated && before == (unsigned)(ow.flush_at - 1)) {
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        if (!owned_row<MODEL>(r)) continue;
+                        int width; T* row = row_ptr<MODEL, T>(m, tp[b], r, width);
+                        T* a = acc + (size_t)sl * ow.acc_width + owned_off<MODEL>(r, m.K);
+#pragma unroll
+                        for (int j = 0; j < EPL; j++) { const int k = g + LPT * j; if (k < width) unsafeAtomicAdd(row + k, lds_take(a + k)); }
+                    }
+                }
             }
         }
         if constexpr (NB == 2) {
@@ -193,6 +296,7 @@ __global__ void __launch_bounds__(256) sgd_hogwild_kernel(DevModel m, const int4
             if (p && !folded_bias) scatter(p, delta, bs, ((atomic >> 8) & 1) && !bias_hot);
         }
         bs = bn; bias_hot = bias_hot_n; hf = hfn;
+        b_p = b_n; b_n = b_nn;
 #pragma unroll
         for (int b = 0; b < B; b++) {
             tp[b] = tn[b]; tn[b] = tnn[b];
@@ -200,6 +304,32 @@ __global__ void __launch_bounds__(256) sgd_hogwild_kernel(DevModel m, const int4
             for (int r = 0; r < R; r++)
 #pragma unroll
                 for (int j = 0; j < EPL; j++) v[b][r][j] = vn[b][r][j];
+        }
+    }
+
+    if constexpr (OWNER) {
+        // what is still pending goes to memory: one group per accumulator row
+#ifdef OWNER_STAMPS
+        const unsigned long long stamp_w = __builtin_amdgcn_s_memrealtime();
+#endif
+        __syncthreads();
+#ifdef OWNER_STAMPS
+        if ((threadIdx.x & 63) == 0) {
+            unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            printf("STAMP %d %d %d %llu %llu %llu %lld\n", (int)blockIdx.x, (int)(threadIdx.x >> 6), (int)(xcc & 15), stamp0, stamp_w, (unsigned long long)__builtin_amdgcn_s_memrealtime(), (long long)n);
+        }
+#endif
+        for (int sl = (int)gid; sl < ow.rows_res; sl += (int)ngroups) {
+            if (pend[sl] == 0) continue;
+            const int4 t = (MODEL == REC_BPRMF || MODEL == REC_MC) ? make_int4(0, 0, slice_base + sl, 0) : make_int4(0, 0, 0, slice_base + sl);
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if (!owned_row<MODEL>(r)) continue;
+                int width; T* row = row_ptr<MODEL, T>(m, t, r, width);
+                const T* a = acc + (size_t)sl * ow.acc_width + owned_off<MODEL>(r, m.K);
+#pragma unroll
+                for (int j = 0; j < EPL; j++) { const int k = g + LPT * j; if (k < width) unsafeAtomicAdd(row + k, a[k]); }
+            }
         }
     }
 
@@ -251,43 +381,76 @@ __global__ void __launch_bounds__(256) project_rows_kernel(T* __restrict__ tab, 
     }
 }
 
+// slices of the catalog in owner mode: one workgroup each, all resident at once on 256 CUs
+constexpr int OWNER_SLICES = 256;
+constexpr size_t OWNER_LDS_BYTES = 160 * 1024 - 2048;   // per workgroup, less what the kernel declares statically
+
+bool sgd_owner_supported(int model)
+{
+    return model == REC_BPRMF || model == REC_MC || model == REC_FPMC || model == REC_PRME || model == REC_HRM_AVG ||
+           model == REC_HRM_MAX || model == REC_TRANSREC || model == REC_TRANSREC_L1;
+}
+int sgd_owner_slices() { return OWNER_SLICES; }
+int sgd_owner_slice_rows(const DevModel& m) { return (m.I + OWNER_SLICES - 1) / OWNER_SLICES; }
+int sgd_owner_neg_field(int model) { return (model == REC_BPRMF || model == REC_MC) ? 2 : 3; }
+
 template <int MODEL, class T>
-static int dispatch_shape(const DevModel& m, const int4* tuples, int64_t n, double lr, int atomic, hipStream_t st)
+static int dispatch_shape(const DevModel& m, const int4* tuples, int64_t n, double lr, int atomic, const int64_t* qoff, int flush_at, hipStream_t st)
 {
     const int Kmax = m.K > m.KK ? m.K : m.KK;
-    // 2048 blocks of 256 threads keep 8 blocks per CU resident; groups stride over the batches
-    auto go = [&](auto kern, int lpt, int b) {
+    OwnerArgs ow = {nullptr, 0, 0, 0, 1};
+    size_t lds = 0;
+    if (qoff) {
+        ow.qoff = qoff; ow.slice_rows = sgd_owner_slice_rows(m); ow.flush_at = flush_at < 1 ? 1 : flush_at;
+        ow.acc_width = (MODEL == REC_FPMC || MODEL == REC_PRME) ? m.K + m.KK : m.K;
+        const size_t per_row = (size_t)ow.acc_width * sizeof(T) + sizeof(unsigned);
+        ow.rows_res = (int)std::min<size_t>((size_t)ow.slice_rows, OWNER_LDS_BYTES / per_row);
+        lds = (size_t)ow.rows_res * per_row;
+    }
+    // plain mode: 2048 blocks of 256 threads keep 8 blocks per CU resident; groups stride over the batches
+    auto go = [&](auto kern, auto kern_owner, int lpt, int b) -> int {
+        if (qoff) {
+            HIP_TRY(hipFuncSetAttribute((const void*)kern_owner, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern_owner, dim3(OWNER_SLICES), dim3(OWNER_THREADS), lds, st, m, tuples, n, (T)lr, atomic, ow);
+            return 0;
+        }
         const int64_t groups_per_block = 256 / lpt;
         int64_t blocks = ((n + b - 1) / b + groups_per_block - 1) / groups_per_block;
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, m, tuples, n, (T)lr, atomic);
+        HIP_TRY(hipMemsetAsync(m.work_counter, 0, sizeof(int), st));   // the batch counter the groups claim from
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, m, tuples, n, (T)lr, atomic, ow);
+        return 0;
     };
     constexpr int R = Spec<MODEL>::R;
     constexpr int B1 = R <= 4 ? 4 : 2;  // tuples in flight per group, by register budget
-    if (Kmax <= 16) go(sgd_hogwild_kernel<MODEL, T, 16, 1, B1>, 16, B1);
-    else if (Kmax <= 32) go(sgd_hogwild_kernel<MODEL, T, 32, 1, B1>, 32, B1);
+    int rc = 0;
+#define SHAPE(LPT, EPL, BB) rc = go(sgd_hogwild_kernel<MODEL, T, LPT, EPL, BB, false>, sgd_hogwild_kernel<MODEL, T, LPT, EPL, BB, true>, LPT, BB)
+    if (Kmax <= 16) SHAPE(16, 1, B1);
+    else if (Kmax <= 32) SHAPE(32, 1, B1);
     // 32 lanes per tuple from K = 33 on: a wave-instruction then serves two tuples with two 128-byte row segments
     // (the shape float atomics still run at full rate on) and the per-tuple arithmetic costs half the issue slots
-    else if (Kmax <= 64) go(sgd_hogwild_kernel<MODEL, T, 32, 2, B1>, 32, B1);
-    else if (Kmax <= 128) go(sgd_hogwild_kernel<MODEL, T, 32, 4, 2>, 32, 2);
-    else if (Kmax <= 256) go(sgd_hogwild_kernel<MODEL, T, 64, 4, 1>, 64, 1);
+    else if (Kmax <= 64) SHAPE(32, 2, B1);
+    else if (Kmax <= 128) SHAPE(32, 4, 2);
+    else if (Kmax <= 256) SHAPE(64, 4, 1);
     else { rec_set_error("K > 256 is not supported"); return -1; }
+#undef SHAPE
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 template <class T>
-static int dispatch_model(const DevModel& m, const int4* tuples, int64_t n, double lr, int atomic, hipStream_t st)
+static int dispatch_model(const DevModel& m, const int4* tuples, int64_t n, double lr, int atomic, const int64_t* qoff, int flush_at, hipStream_t st)
 {
     switch (m.model) {
-    case REC_BPRMF: return dispatch_shape<REC_BPRMF, T>(m, tuples, n, lr, atomic, st);
-    case REC_MC: return dispatch_shape<REC_MC, T>(m, tuples, n, lr, atomic, st);
-    case REC_FPMC: return dispatch_shape<REC_FPMC, T>(m, tuples, n, lr, atomic, st);
-    case REC_PRME: return dispatch_shape<REC_PRME, T>(m, tuples, n, lr, atomic, st);
-    case REC_HRM_AVG: return dispatch_shape<REC_HRM_AVG, T>(m, tuples, n, lr, atomic, st);
-    case REC_HRM_MAX: return dispatch_shape<REC_HRM_MAX, T>(m, tuples, n, lr, atomic, st);
-    case REC_TRANSREC: return dispatch_shape<REC_TRANSREC, T>(m, tuples, n, lr, atomic, st);
-    case REC_TRANSREC_L1: return dispatch_shape<REC_TRANSREC_L1, T>(m, tuples, n, lr, atomic, st);
+    case REC_BPRMF: return dispatch_shape<REC_BPRMF, T>(m, tuples, n, lr, atomic, qoff, flush_at, st);
+    case REC_MC: return dispatch_shape<REC_MC, T>(m, tuples, n, lr, atomic, qoff, flush_at, st);
+    case REC_FPMC: return dispatch_shape<REC_FPMC, T>(m, tuples, n, lr, atomic, qoff, flush_at, st);
+    case REC_PRME: return dispatch_shape<REC_PRME, T>(m, tuples, n, lr, atomic, qoff, flush_at, st);
+    case REC_HRM_AVG: return dispatch_shape<REC_HRM_AVG, T>(m, tuples, n, lr, atomic, qoff, flush_at, st);
+    case REC_HRM_MAX: return dispatch_shape<REC_HRM_MAX, T>(m, tuples, n, lr, atomic, qoff, flush_at, st);
+    case REC_TRANSREC: return dispatch_shape<REC_TRANSREC, T>(m, tuples, n, lr, atomic, qoff, flush_at, st);
+    case REC_TRANSREC_L1: return dispatch_shape<REC_TRANSREC_L1, T>(m, tuples, n, lr, atomic, qoff, flush_at, st);
     default:
         rec_set_error("Hogwild update kernel not available for this model");
         return -1;
@@ -298,8 +461,17 @@ int launch_sgd_hogwild(const DevModel& m, int precision, const int4* tuples, int
                        hipStream_t st)
 {
     if (n <= 0) return 0;
-    return precision == REC_F64 ? dispatch_model<double>(m, tuples, n, lr, atomic, st)
-                                : dispatch_model<float>(m, tuples, n, lr, atomic, st);
+    return precision == REC_F64 ? dispatch_model<double>(m, tuples, n, lr, atomic, nullptr, 1, st)
+                                : dispatch_model<float>(m, tuples, n, lr, atomic, nullptr, 1, st);
+}
+
+int launch_sgd_owner(const DevModel& m, int precision, const int4* partitioned, const int64_t* qoff, int64_t n, double lr, int atomic,
+                     int flush_at, hipStream_t st)
+{
+    if (n <= 0) return 0;
+    if (!qoff) { rec_set_error("owner mode needs the slice offsets"); return -1; }
+    return precision == REC_F64 ? dispatch_model<double>(m, partitioned, n, lr, atomic, qoff, flush_at, st)
+                                : dispatch_model<float>(m, partitioned, n, lr, atomic, qoff, flush_at, st);
 }
 
 int launch_apply_global(const DevModel& m, int precision, double lr, int64_t n_tuples, double cap, hipStream_t st)

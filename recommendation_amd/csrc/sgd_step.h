@@ -61,6 +61,24 @@ __device__ __forceinline__ int row_item(const int4& t, int r)
     else return r == 0 ? -1 : r == 1 ? t.y : r == 2 ? t.z : t.w;   // HRM, TransRec
 }
 
+// table of row r of a tuple, and the row's number in it (row_ptr = row_table + row_number * width)
+template <int MODEL, class T>
+__device__ __forceinline__ T* row_table(const DevModel& m, int r)
+{
+    if constexpr (MODEL == REC_BPRMF) return (T*)m.tab[r == 0 ? BPRMF_GU : BPRMF_GI];
+    else if constexpr (MODEL == REC_MC) return (T*)m.tab[r == 0 ? MC_GI : MC_ETA];
+    else if constexpr (MODEL == REC_FPMC) return (T*)m.tab[r == 0 ? FPMC_GU : r < 3 ? FPMC_GI : r == 3 ? FPMC_KAPPA : FPMC_ETA];
+    else if constexpr (MODEL == REC_PRME) return (T*)m.tab[r == 0 ? PRME_GU : r < 3 ? PRME_GI : PRME_ETA];
+    else if constexpr (MODEL == REC_HRM_AVG || MODEL == REC_HRM_MAX) return (T*)m.tab[r == 0 ? HRM_U : HRM_V];
+    else return (T*)m.tab[r == 0 ? TR_R : TR_H];
+}
+template <int MODEL>
+__device__ __forceinline__ int row_number(const int4& t, int r)
+{
+    const int item = row_item<MODEL>(t, r);
+    return item >= 0 ? item : t.x;   // rows without an item are indexed by the tuple's user
+}
+
 template <int MODEL, class T>
 __device__ __forceinline__ T* bias_ptr(const DevModel& m, const int4& t, int s)
 {
@@ -68,13 +86,39 @@ __device__ __forceinline__ T* bias_ptr(const DevModel& m, const int4& t, int s)
     else return (T*)m.tab[TR_BETA] + (s == 0 ? t.z : t.w);
 }
 
-// ---- the step itself: rows v[R][EPL] and biases b[2] in, deltas out (in place)
-template <int MODEL, class T, int LPT, int EPL>
+// ---- owner mode (see sgd_hogwild.hip)
+// rows of a tuple indexed by its negative item, and where each sits inside the item's accumulator row
+template <int MODEL> __device__ __forceinline__ constexpr bool owned_row(int r)
+{
+    if constexpr (MODEL == REC_BPRMF || MODEL == REC_MC) return r == 2;
+    else if constexpr (MODEL == REC_FPMC || MODEL == REC_PRME) return r == 2 || r == 5;
+    else return r == 3;   // HRM, TransRec
+}
+template <int MODEL> __device__ __forceinline__ int owned_off(int r, int K) { return ((MODEL == REC_FPMC || MODEL == REC_PRME) && r == 5) ? K : 0; }
+template <int MODEL> __device__ __forceinline__ int neg_item(const int4& t) { return (MODEL == REC_BPRMF || MODEL == REC_MC) ? t.z : t.w; }
+
+// reads an LDS accumulator element and leaves zero behind, atomically per element (an addition by another group lands
+// either before the exchange, and is taken, or after it, and stays for the next flush)
+__device__ __forceinline__ float lds_take(float* p) { return __uint_as_float(atomicExch((unsigned*)p, 0u)); }
+__device__ __forceinline__ double lds_take(double* p) { return __longlong_as_double((long long)atomicExch((unsigned long long*)p, 0ull)); }
+
+struct OwnerArgs {
+    const int64_t* qoff;   // [slices + 1] where each slice's tuples start in the partitioned buffer
+    int slice_rows;        // items per slice
+    int rows_res;          // items of a slice with an accumulator row in LDS
+    int acc_width;         // elements of an accumulator row (K, or K + KK)
+    int flush_at;          // additions after which a row's accumulator is moved to memory
+};
+
+// ------------------------------------------------------------------------------------------------
+// ---- the step itself: rows v[R][EPL] and biases b[2] in, deltas out (in place).  LAYOUT: which components lane g
+// holds - 0: g, g + LPT, ... (one dword per lane and access), 1: EPL * g .. EPL * g + EPL - 1 (one wide access per row)
+template <int MODEL, class T, int LPT, int EPL, int LAYOUT = 0>
 __device__ __forceinline__ T step(const DevModel& m, T lr, int g, T (&v)[Spec<MODEL>::R][EPL], T b0, T b1,
                                   const T (&rg)[EPL], T (&racc)[EPL], const bool (&at)[Spec<MODEL>::R])
 {
     const T lam = (T)m.lambda;
-    auto gsum = [](T x) { return group_sum<LPT>(x); };
+    auto gsum = [](T x) { return group_sum_dpp<LPT>(x); };
     if constexpr (MODEL == REC_BPRMF) {
         // BPRMF.cpp:85-105
         T s = 0;
@@ -190,7 +234,7 @@ __device__ __forceinline__ T step(const DevModel& m, T lr, int g, T (&v)[Spec<MO
         T nw[3][EPL]; T sq[3] = {0, 0, 0};
 #pragma unroll
         for (int j = 0; j < EPL; j++) {
-            const bool live = g + LPT * j < m.K;
+            const bool live = (LAYOUT == 0 ? g + LPT * j : EPL * g + j) < m.K;
             T gx, gy, gn, gr;
             if (!L1) {
                 gx = deri * 2 * (-d[j] + dn[j]) - lam * h[0][j];

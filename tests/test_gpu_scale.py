@@ -74,7 +74,11 @@ def test_full_shape_sampler_support(big):
     for u, p, n, _ in T[:20000].tolist():
         s = seq_item[seq_off[u]:seq_off[u + 1]]
         assert (s == p).any() and not (s == n).any()     # BPRMF.cpp:74-83, 135-143
-    assert (T[0::2, 2] == T[1::2, 2]).mean() > 0.99       # the default at this size: pairs of steps share their negative
+    assert (T[0::2, 2] == T[1::2, 2]).mean() < 1e-3       # the default: every step draws its own negative, as the reference does
+    eng.set_option("share_negative", 2)                   # option: pairs of steps take their negative from one candidate stream
+    T2 = eng.sample_tuples(1 << 16, seed=9, epoch=4)
+    eng.set_option("share_negative", 1)
+    assert (T2[0::2, 2] == T2[1::2, 2]).mean() > 0.99
     # users uniform: the mean user id of 1M draws is within 5 sigma of (U - 1) / 2
     assert abs(T[:, 0].mean() - (U - 1) / 2) < 5 * U / np.sqrt(12 * len(T))
 
