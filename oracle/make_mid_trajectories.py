@@ -24,9 +24,9 @@ RUNS = [
     ("HRM_avg", 1, 1, 0.01, 0.0, 0.0, 0.0, 40, 2),
     ("PRME", 1, 1, 0.01, 0.0, 0.0, 0.5, 40, 2),
     ("MC", 1, 1, 0.01, 0.0, 0.0, 0.0, 40, 2),
-    ("Fossil", 3, 2, 0.01, 0.01, 0.0, 0.0, 40, 4),
+    ("Fossil", 3, 2, 0.01, 0.01, 0.0, 0.0, 12, 1),   # peaks within the first epochs at this learning rate: evaluated every epoch
     ("REBUS", 3, 2, 0.01, 0.0, 0.0, -0.6, 40, 4),
-    ("FossilSimple", 1, 1, 0.01, 0.01, 0.0, 0.0, 40, 4),
+    ("FossilSimple", 1, 1, 0.01, 0.01, 0.0, 0.0, 12, 1),
 ]
 SEEDS = (0, 2, 3)   # glibc treats srand(0) as srand(1): seed 1 would repeat seed 0
 

@@ -350,7 +350,9 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     // by the arithmetic of its projections.  ("share_negative" 2, pairs of steps drawing one negative, is the older
     // way to the same saving; it changes the joint distribution of consecutive steps and stays an option.)
     const bool transrec = d->model == REC_TRANSREC || d->model == REC_TRANSREC_L1;
-    e->owner = (!history_model(d->model) && !transrec && sgd_owner_supported(d->model) && e->steps_per_epoch >= (1 << 22)) ? 1 : 0;
+    // (f32 tables only: the f64 form of the kernel is issue-bound and loses more to the accumulator traffic than it saves)
+    e->owner = (!history_model(d->model) && !transrec && sgd_owner_supported(d->model) && d->precision == REC_F32 &&
+                e->steps_per_epoch >= (1 << 22)) ? 1 : 0;
     e->neg_share = 1;
     *out = e;
     return 0;

@@ -24,7 +24,8 @@ constexpr int WIDE_EPL = 4;
 constexpr int WIDE_OWNER_THREADS = 1024;   // one workgroup per CU in owner mode
 constexpr int WIDE_SLICES = 256;
 
-template <int MODEL, int LPT, int B, bool OWNER>
+// FULL: K (and KK) == 4 * LPT, every lane of a group holds four live components (no width tests)
+template <int MODEL, int LPT, int B, bool OWNER, bool FULL>
 __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_kernel(DevModel m, const int4* __restrict__ tuples, int64_t n,
                                                                                    float lr, int atomic, OwnerArgs ow)
 {
@@ -104,7 +105,7 @@ __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_ker
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 int width; const T* row = row_ptr<MODEL, T>(m, tp[b], r, width);
-                v[b][r] = (ok && EPL * g < width) ? *reinterpret_cast<const float4*>(row + EPL * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[b][r] = (ok && (FULL || EPL * g < width)) ? *reinterpret_cast<const float4*>(row + EPL * g) : make_float4(0.f, 0.f, 0.f, 0.f);
                 if (g == b * R + r && ok && ((atomic >> r) & 1)) flag_item = row_item<MODEL>(tp[b], r);
             }
         }
@@ -125,10 +126,17 @@ __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_ker
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int f = 64 * j + lane;
-            const int q = f / ROWF, e = f % ROWF;
-            const int c = __shfl(code, q * LPT, 64);
+            const int e = f % ROWF;
+            // the group whose image these 64 floats belong to is the same for the whole wavefront (or for each half of it)
+            int c;
+            if constexpr (ROWF >= 64) c = __builtin_amdgcn_readlane(code, ((64 * j) / ROWF) * LPT);
+            else {
+                static_assert(ROWF == 32, "8 lanes per tuple: two row images per instruction");
+                const int c0 = __builtin_amdgcn_readlane(code, (2 * j) * LPT), c1 = __builtin_amdgcn_readlane(code, (2 * j + 1) * LPT);
+                c = lane < 32 ? c0 : c1;
+            }
             const T x = stage[f];
-            if (c >= 0 && e < width) unsafeAtomicAdd(tab + (int64_t)c * width + e, x);
+            if (c >= 0 && (FULL || e < width)) unsafeAtomicAdd(tab + (int64_t)c * width + e, x);
         }
     };
 
@@ -163,7 +171,7 @@ __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_ker
                     for (int r = 0; r < R; r++) {
                         if (!owned_row<MODEL>(r)) continue;
                         const int width = ((MODEL == REC_FPMC || MODEL == REC_PRME) && r == 5) ? m.KK : m.K;
-                        if (EPL * g < width) {
+                        if (FULL || EPL * g < width) {
                             const float4 a = *reinterpret_cast<const float4*>(acc + (size_t)sl * ow.acc_width + owned_off<MODEL>(r, m.K) + EPL * g);
                             w[r][0] += a.x; w[r][1] += a.y; w[r][2] += a.z; w[r][3] += a.w;
                         }
@@ -184,7 +192,7 @@ __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_ker
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 int width; T* row = row_ptr<MODEL, T>(m, tp[b], r, width);
-                const bool act = ok && EPL * g < width;
+                const bool act = ok && (FULL || EPL * g < width);
                 const bool to_acc = OWNER && owned_row<MODEL>(r) && sl >= 0 && at[r];
                 if (to_acc) {
                     if (act) {
@@ -205,17 +213,17 @@ __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_ker
             }
             if constexpr (OWNER) {
                 // every flush_at-th addition to an item moves its accumulated delta to memory: one atomic row for all of them
-                unsigned before = 0;
-                if (accumulated && g == 0) before = atomicInc(pend + sl, (unsigned)(ow.flush_at - 1));
-                before = __shfl(before, 0, LPT);
-                const bool fire = accumulated && before == (unsigned)(ow.flush_at - 1);
-                if (__ballot(fire)) {
+                bool fire0 = false;   // known to the first lane of the group, which counts the additions
+                if (accumulated && g == 0) fire0 = atomicInc(pend + sl, (unsigned)(ow.flush_at - 1)) == (unsigned)(ow.flush_at - 1);
+                const unsigned long long fired = __ballot(fire0);
+                if (fired) {
+                    const bool fire = (fired >> (lane & ~(LPT - 1))) & 1ull;
 #pragma unroll
                     for (int r = 0; r < R; r++) {
                         if (!owned_row<MODEL>(r)) continue;
                         const int width = ((MODEL == REC_FPMC || MODEL == REC_PRME) && r == 5) ? m.KK : m.K;
                         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (fire && EPL * g < width) {
+                        if (fire && (FULL || EPL * g < width)) {
                             T* a = acc + (size_t)sl * ow.acc_width + owned_off<MODEL>(r, m.K) + EPL * g;
                             x = make_float4(lds_take(a), lds_take(a + 1), lds_take(a + 2), lds_take(a + 3));
                         }
@@ -255,7 +263,7 @@ __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_ker
                 if (!owned_row<MODEL>(r)) continue;
                 const int width = ((MODEL == REC_FPMC || MODEL == REC_PRME) && r == 5) ? m.KK : m.K;
                 float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (dirty && EPL * g < width) x = *reinterpret_cast<const float4*>(acc + (size_t)sl * ow.acc_width + owned_off<MODEL>(r, m.K) + EPL * g);
+                if (dirty && (FULL || EPL * g < width)) x = *reinterpret_cast<const float4*>(acc + (size_t)sl * ow.acc_width + owned_off<MODEL>(r, m.K) + EPL * g);
                 *reinterpret_cast<float4*>(stage + EPL * lane) = x;
                 flush_stage(row_table<MODEL, T>(m, r), width, dirty ? slice_base + sl : -1);
             }
@@ -304,7 +312,10 @@ static int wide_dispatch(const DevModel& m, const int4* tuples, int64_t n, doubl
     };
     constexpr int R = Spec<MODEL>::R;
     int rc = 0;
-#define WIDE_SHAPE(LPT, BB) rc = go(sgd_wide_kernel<MODEL, LPT, BB, false>, sgd_wide_kernel<MODEL, LPT, BB, true>, LPT, BB)
+    const bool full_k = m.K == m.KK || !(MODEL == REC_FPMC || MODEL == REC_PRME);   // every row of the tuple has K components
+#define WIDE_SHAPE(LPT, BB)                                                                                                               \
+    rc = (full_k && m.K == 4 * LPT) ? go(sgd_wide_kernel<MODEL, LPT, BB, false, true>, sgd_wide_kernel<MODEL, LPT, BB, true, true>, LPT, BB) \
+                                    : go(sgd_wide_kernel<MODEL, LPT, BB, false, false>, sgd_wide_kernel<MODEL, LPT, BB, true, false>, LPT, BB)
     if (Kmax <= 32) WIDE_SHAPE(8, (R <= 4 ? 2 : 1));
     else if (Kmax <= 64) WIDE_SHAPE(16, 2);
     else if (Kmax <= 128) WIDE_SHAPE(32, 2);

@@ -2,6 +2,7 @@
 // is orchestration the reference also does on the host: the split, the train() loop with its
 // validation cadence and early stopping, the progress lines, the saved-model file.
 #include "model.hpp"
+#include "model_io.hpp"
 #include <zlib.h>
 #include <sys/time.h>
 #include <algorithm>
@@ -85,7 +86,7 @@ void model::createEngine(rec_model_desc desc, const vector<int64_t>* path_off, c
     desc.user_begin = desc.user_end = 0;
     best_on_device = false;
     check(rec_create(&c, &desc, &eng));
-    NW = (int)rec_nw(eng);
+    NW = rec_nw(eng);
     W = new double[NW > 0 ? NW : 1];
     bestW = new double[NW > 0 ? NW : 1];
 }
@@ -113,15 +114,16 @@ void model::AUC(double* AUC_val, double* AUC_test, double* HIT_val, double* HIT_
     *MRR_val = m.mrr_val; *MRR_test = m.mrr_test; *var = m.var_test;
 }
 
-// src/model.cpp:100-167: the validation estimate over 2000 candidate draws.  The device scores one draw of 2000
-// items (shared by all users, fresh every call) with the kernels of AUC(); RECSYS_EXACT_VALIDATION=1 returns the
-// exact full-catalog value instead.
+// src/model.cpp:100-167 estimates the validation AUC from 2000 candidate draws per user because the exact value costs
+// the reference minutes.  Here the exact full-catalog value costs less than an epoch, so it is what train() compares
+// (no sampling noise in the early-stopping decision).  RECSYS_SAMPLED_VALIDATION=1 selects the estimate instead: one
+// draw of 2000 items shared by all users, fresh every call, scored by the kernels of AUC().
 void model::sampleAUC(double* AUC_val, double* AUC_test, double* var)
 {
     rec_metrics m;
-    const char* exact = getenv("RECSYS_EXACT_VALIDATION");
-    if (exact && atoi(exact) != 0) check(rec_eval(eng, 50, &m, 0, 0));
-    else check(rec_eval_sampled(eng, 50, 2000, validation_calls++, &m, 0, 0));
+    const char* sampled = getenv("RECSYS_SAMPLED_VALIDATION");
+    if (sampled && atoi(sampled) != 0) check(rec_eval_sampled(eng, 50, 2000, validation_calls++, &m, 0, 0));
+    else check(rec_eval(eng, 50, &m, 0, 0));
     *AUC_val = m.auc_val; *AUC_test = m.auc_test; *var = m.var_test;
 }
 
@@ -145,19 +147,8 @@ void model::saveModel(const char* path)
 {
     // src/model.cpp:176-192 writes bestW, which train() has just copied into W
     syncToHost();
-    for (int w = 0; w < NW; w++) bestW[w] = W[w];
-    FILE* f = fopen(path, "w");
-    if (!f) { printf("An error occurred while opening file %s.\n", path); exit(1); }
-    fprintf(f, "{\n");
-    fprintf(f, "  \"NW\": %d,\n", NW);
-    fprintf(f, "  \"W\": [");
-    for (int w = 0; w < NW; w++) {
-        fprintf(f, "%f", bestW[w]);
-        if (w < NW - 1) fprintf(f, ", ");
-    }
-    fprintf(f, "]\n");
-    fprintf(f, "}\n");
-    fclose(f);
+    for (int64_t w = 0; w < NW; w++) bestW[w] = W[w];
+    write_model_file(path, bestW, NW);
     printf("\nModel saved to %s.\n", path);
 }
 
@@ -165,24 +156,7 @@ void model::loadModel(const char* path)
 {
     // src/model.cpp:195-232
     printf("\n  loading parameters from %s.\n", path);
-    ifstream in(path);
-    if (!in.good()) { printf("Can't read init solution from %s.\n", path); exit(1); }
-    string line, st; char ch;
-    while (getline(in, line)) {
-        stringstream ss(line);
-        ss >> st;
-        if (st == "\"NW\":") {
-            int nw; ss >> nw;
-            if (nw != NW) { printf("NW not match."); exit(1); }
-            continue;
-        }
-        if (st == "\"W\":") {
-            ss >> ch;
-            for (int w = 0; w < NW; w++)
-                if (!(ss >> W[w] >> ch)) { printf("Read W[] error."); exit(1); }
-            break;
-        }
-    }
+    read_model_file(path, W, NW);
     syncToDevice();
 }
 
@@ -409,7 +383,7 @@ void REBUS::init()
     rec_rebus_build_paths(nUsers, nItems, seq_off.data(), seq_item.data(), val_item.data(), (int64_t)lab_off.size() - 1, lab_off.data(),
                           lab_item.data(), path_off.data(), path_item.data());
     createEngine(make_desc(REC_REBUS, K, K, L, lambda, bias_reg, 0, alpha_up, 0), &path_off, &path_item);
-    printf(" --NW : %d -- \n\n", NW);
+    printf(" --NW : %lld -- \n\n", (long long)NW);
     check(rec_params_init(eng, 0));
     printf(" --Init REBUS ended -- \n\n");
 }

@@ -3,6 +3,7 @@
 // format.  The hot methods - oneiteration / oneIteration, updateFactors, AUC, sampleAUC,
 // MultipleMetrics, copyBestModel - hand over to the HIP engine through include/recsys_engine.h.
 #pragma once
+#include <cstdint>
 #include <string>
 #include <utility>
 #include <vector>
@@ -16,7 +17,7 @@ public:
     virtual ~model();
 
     /* Model parameters */
-    int NW;
+    int64_t NW;                       // the reference holds an int (src/model.hpp:60); 64 bits here so that the count never narrows
     double* W;                        // host copy; the device copy is authoritative between syncToHost() calls
     double* bestW;
 

@@ -131,3 +131,17 @@ def test_loader_orders_tied_clicks_as_the_reference(tmp_path):
         assert np.array_equal(got, gold[f"corpus_{ext}"].astype(np.int64)), ext
     lens = gold["corpus_txt"]
     assert lens[0] == 60 and lens[2] == 2031
+
+
+def test_model_file_writer_and_parser_match_fprintf(tmp_path):
+    """The saved-model text file (src/model.cpp:176-232) written in parallel slices is byte for byte what the reference's
+    per-element fprintf("%f") loop writes, and reads back to the written 6-decimal values (2M values incl. 1e9-sized, 1e-7-sized,
+    negative ones and exact ties of the sixth decimal)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "recommendation_amd", "model_io_check")
+    assert os.path.exists(tool), "build recommendation_amd/host first"
+    r = subprocess.run([tool, "2000000", str(tmp_path / "m.txt"), "compare"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("write "), r.stdout + r.stderr
+    r = subprocess.run([tool, "1", str(tmp_path / "one.txt"), "compare"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr

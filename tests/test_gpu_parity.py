@@ -31,17 +31,28 @@ def test_sequential_replay_f64_matches_reference(model):
 
 
 @pytest.mark.parametrize("model", TOY_MODELS)
-def test_sequential_replay_f32_within_1e5(model):
+def test_sequential_replay_f32_bounds(model):
+    """Criterion (a) with f32 tables: all 2000 fixture tuples (every row is rewritten ~100 times in place, each write
+    rounded to f32) against the fp64 restatement started from the same f32-rounded values.  The 1e-5 relative bound per
+    parameter is met by the f64 mode (test above, 1e-10).  With f32 storage it holds relative to max(|w|, 0.1) - an
+    absolute error below 1e-6 on parameters of size 0.1 .. 1 (measured <= 2.7e-6 of that scale) - while the pure
+    relative error of small parameters (1e-3 <= |w|, left over from cancellations) reaches 1e-4 after 2000 steps and
+    stays below 2e-5 after 200: both are asserted."""
     g, model, co, ci, labels = fixture_case(model, "toy")
-    e = make_engine(g, model, co, ci, labels, F32)
-    e.upload(g["W0"])
-    n = 200  # f32 rounding grows with the number of in-place steps; 200 steps stay inside the 1e-5 bound
-    e.sgd_replay(float(g["lr"]), g["tuples"][:n], SEQUENTIAL)
-    W1 = e.download()
     o = make_oracle(g, model, co, ci, labels)
-    ref = o.replay(g["W0"].astype(np.float32).astype(np.float64), g["tuples"][:n], float(g["lr"]))
-    assert rel_err(W1, ref, floor=1e-1) < 1e-5, (model, rel_err(W1, ref, floor=1e-1))
-    e.close()
+    W0 = g["W0"].astype(np.float32).astype(np.float64)
+    for n, rel_bound in ((200, 2e-5), (2000, 2e-4)):
+        e = make_engine(g, model, co, ci, labels, F32)
+        e.upload(g["W0"])
+        e.sgd_replay(float(g["lr"]), g["tuples"][:n], SEQUENTIAL)
+        W1 = e.download()
+        ref = o.replay(W0, g["tuples"][:n], float(g["lr"]))
+        big = np.abs(ref) >= 1e-3
+        rel = float(np.max(np.abs(W1[big] - ref[big]) / np.abs(ref[big]))) if big.any() else 0.0
+        small = float(np.max(np.abs(W1[~big] - ref[~big]))) if (~big).any() else 0.0
+        assert rel_err(W1, ref, floor=1e-1) < 5e-6, (model, n, rel_err(W1, ref, floor=1e-1))
+        assert rel < rel_bound and small < 2e-7, (model, n, rel, small)
+        e.close()
 
 
 @pytest.mark.parametrize("model", EVAL_MODELS)
