@@ -196,6 +196,7 @@ def main():
     ap.add_argument("--cpu-ref-eval-users", type=int, default=1000, help="users the reference binary's model::AUC is timed on (0 = skip)")
     ap.add_argument("--wide", type=int, default=-1, help="wide: the four-components-per-lane form of the update kernel (0, 1); -1 = engine default")
     ap.add_argument("--atomic-mask", type=int, default=-1, help="experiment: the engine's 'atomic' row mask (bit r = row r of the tuple, bit 8 = biases)")
+    ap.add_argument("--rounds", type=int, default=0, help="N > 1: item-table all-reduces per epoch (0 = the accuracy-preserving default, ceil(steps / (2 items)))")
     ap.add_argument("--no-variants", action="store_true", help="skip the extra measurements of the other scatter modes and of f64 storage")
     ap.add_argument("--cpu-eval-users", type=int, default=16384, help="users of the CPU evaluation baseline (0 = skip)")
     ap.add_argument("--cpu-ref-users", type=int, default=60000, help="users of the click file the reference binary is timed on (0 = skip)")
@@ -320,20 +321,17 @@ def main():
             acc += float(np.mean(sizes))   # target positions 1 .. n-1: prefix of 1 .. n-1 items
         rebus_rows = acc / len(sample_u)
 
-    def measure(e, md, prec_name, steps, warmup, item_tabs=(), epoch0=0):
+    def measure(e, md, prec_name, steps, warmup, trainer=None, epoch0=0):
         """steps timed SGD epochs on engine e -> the fields of one bench entry."""
         esz_ = 4 if prec_name == "f32" else 8
 
         def one_step(epoch):
-            for t, base in item_tabs:
-                base.copy_(t)
-            if item_tabs:
+            if trainer is not None:
+                trainer.epoch(0.05, seed=99, epoch=epoch)      # rounds of local steps + item-table all-reduce (sharded.py)
                 torch.cuda.synchronize()
-            e.sgd_epoch(0.05, my_steps, seed=99, epoch=epoch * world + rank)
-            e.sync()
-            if item_tabs:
-                combine_item_tables([t for t, _ in item_tabs], [b for _, b in item_tabs], world, lambda t: all_reduce(t, dist.ReduceOp.SUM))
-                torch.cuda.synchronize()
+            else:
+                e.sgd_epoch(0.05, my_steps, seed=99, epoch=epoch * world + rank)
+                e.sync()
 
         for w in range(warmup):
             one_step(epoch0 + w)
@@ -416,15 +414,17 @@ def main():
         return {"value": round(total_triples / dt, 1), "ms_per_step": round(dt / steps * 1e3, 3), "dtype": prec_name,
                 "update": update, "roofline": roof}
 
-    # item tables (replicated) as torch tensors over engine memory, for the all-reduce
-    item_tabs = []
+    # N ranks: every rank trains its own users; the replicated item tables are combined after every round
+    trainer = None
     if world > 1:
-        for ptr, rows_, cols, is_user in eng.tables():
-            if not is_user:
-                t = torch.as_tensor(DevArray(ptr, (rows_ * cols,), "<f4" if prec == F32 else "<f8"), device=dev)
-                item_tabs.append((t, torch.empty_like(t)))
+        from recommendation_amd.sharded import ShardedTrainer
+        trainer = ShardedTrainer(eng, rank, world, lambda t: all_reduce(t, dist.ReduceOp.SUM), dev,
+                                 rounds=args.rounds if args.rounds > 0 else None)
+        my_steps = trainer.steps_per_round() * trainer.rounds
+        if trainer.steps_per_round() < (1 << 20):
+            mode["owner"] = 0
 
-    main_res = measure(eng, mode, args.precision, args.steps, args.warmup, item_tabs)
+    main_res = measure(eng, mode, args.precision, args.steps, args.warmup, trainer)
     roofline = main_res["roofline"]
     roofline["tuples_drawn_over_expected"] = round(eng.tuples_drawn / max(1, my_steps * (args.steps + args.warmup)), 6)
     # practical ceiling: a device-to-device copy of 1 GiB (read + write counted)
@@ -444,7 +444,8 @@ def main():
            "data": "synthetic",
            "config": {"workload": f"{args.model} K={K} oneiteration (BPR-SGD epoch) on synthetic {U} users x {I} items x "
                                   f"{n_clicks} interactions", "triples_per_step": my_steps * world,
-                      "update": main_res["update"], "parallelism": f"user-sharded x{world}"},
+                      "update": main_res["update"], "parallelism": f"user-sharded x{world}" + (
+                          f", item tables all-reduced (sum of deltas) {trainer.rounds} times per epoch, {sum(t.numel() * t.element_size() for t in trainer.tabs)} bytes each" if trainer else "")},
            "roofline": roofline}
 
     # ---------------- the other scatter modes and f64 storage, same corpus, same measurement (N=1 only)

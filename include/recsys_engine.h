@@ -62,7 +62,9 @@ typedef struct {
     int32_t dataset_factor;   /* Fossil.hpp:22; 0 selects the reference's 10 */
     int32_t precision;        /* enum rec_precision: storage and arithmetic type of the SGD step */
     int32_t device;           /* HIP device ordinal */
-    int32_t user_begin, user_end; /* users this engine samples and evaluates; 0,0 = all */
+    int32_t user_begin, user_end; /* users this engine samples and evaluates (MC samples the same share of the source items);
+                                     0,0 = all.  Rows indexed by user, sequences, click sets and REBUS paths of other users
+                                     are not kept on the device, and tuples naming them are rejected. */
 } rec_model_desc;
 
 /* Outputs of model::AUC (src/model.cpp:3-98) */
@@ -176,7 +178,9 @@ int64_t rec_fsub_mine(int32_t n_users, int32_t n_items, const int64_t* seq_off, 
 
 /* Device tables, for collectives issued by the caller (RCCL through torch.distributed):
  * table t of the model in the reference's flat order.  *dev_ptr points to rows x cols elements
- * of the engine's precision, contiguous.  is_user_table = 1 for tables indexed by user. */
+ * of the engine's precision, contiguous.  is_user_table = 1 for tables indexed by user: of those only the rows of the
+ * engine's own users [user_begin, user_end) are resident (dev_ptr is where row 0 would be; dev_ptr + user_begin * cols
+ * is the first row that exists), and rec_params_upload / rec_params_download move only those rows. */
 int rec_num_tables(const rec_engine* e);
 int rec_table_info(const rec_engine* e, int t, void** dev_ptr, int64_t* rows, int64_t* cols, int* is_user_table);
 

@@ -124,6 +124,7 @@ class Engine:
                             device, user_begin, user_end)
         _check(lib().rec_create(C.byref(corpus), C.byref(desc), C.byref(self.handle)))
         self.precision = precision
+        self.user_begin, self.user_end = (0, self.n_users) if (user_begin == 0 and user_end == 0) else (user_begin, user_end)
 
     def close(self):
         if self.handle:

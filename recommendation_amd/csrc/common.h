@@ -13,6 +13,7 @@
 // Everything a kernel needs to know about the model and the corpus; passed by value.
 struct DevModel {
     int model, U, I, K, KK, L;
+    int user_begin, user_end;           // the engine's own users: only their rows, sequences, click sets and paths are resident
     double lambda, bias_reg, relation_reg, alpha, df;
     void* tab[REC_MAX_TABLES];          // device tables in the reference's flat order, rows contiguous
     const int64_t* seq_off;             // [U+1] training sequences

@@ -13,8 +13,9 @@ static bool history_model(int model);
 extern "C" const char* rec_last_error(void) { return g_err.c_str(); }
 
 struct TableDesc {
-    int64_t host_off, rows, cols, dev_off;  // offsets in elements
+    int64_t host_off, rows, cols, dev_off;  // offsets in elements; dev_off: where the table's first RESIDENT row sits in W
     int is_user;
+    int64_t row0, nrows;                    // resident rows [row0, row0 + nrows): all of them, or the engine's users' rows
 };
 
 struct rec_engine {
@@ -110,11 +111,26 @@ static int upload(rec_engine* e, const std::vector<T>& h, const T** dev)
     return 0;
 }
 
+// uploads h[first, first + count) and returns the address element 0 WOULD have: kernels keep indexing with global
+// positions, only [first, first + count) may be touched
+template <class T>
+static int upload_range(rec_engine* e, const std::vector<T>& h, int64_t first, int64_t count, const T** dev)
+{
+    void* p = nullptr;
+    ENG_HIP(hipMalloc(&p, std::max<size_t>((size_t)count * sizeof(T), 8)));
+    e->owned.push_back(p);
+    if (count > 0) ENG_HIP(hipMemcpy(p, h.data() + first, (size_t)count * sizeof(T), hipMemcpyHostToDevice));
+    *dev = (const T*)p - first;
+    return 0;
+}
+
 static void build_tables(rec_engine* e)
 {
     const int64_t U = e->U, I = e->I, K = e->desc.K, KK = e->desc.KK, L = e->desc.L;
     std::vector<TableDesc>& t = e->tables;
-    auto add = [&](int64_t rows, int64_t cols, int is_user) { t.push_back({0, rows, cols, 0, is_user}); };
+    // a table indexed by user only holds the rows of the engine's own users [user_begin, user_end)
+    const int64_t ub = e->desc.user_begin, ue = e->desc.user_end;
+    auto add = [&](int64_t rows, int64_t cols, int is_user) { t.push_back({0, rows, cols, 0, is_user, is_user ? ub : 0, is_user ? ue - ub : rows}); };
     switch (e->desc.model) {
     case REC_BPRMF: add(I, 1, 0); add(U, K, 1); add(I, K, 0); break;                       // BPRMF.cpp:49-61
     case REC_MC: add(I, K, 0); add(I, K, 0); break;                                        // MC.cpp:59-67
@@ -131,7 +147,7 @@ static void build_tables(rec_engine* e)
     for (auto& d : t) {
         d.host_off = ho; d.dev_off = dv;
         ho += d.rows * d.cols;
-        dv = align_up(dv + d.rows * d.cols, 256 / e->elem_size);  // every table starts on a 256-byte boundary
+        dv = align_up(dv + d.nrows * d.cols, 256 / e->elem_size);  // every table starts on a 256-byte boundary
     }
     e->nw = ho; e->dev_elems = std::max<int64_t>(dv, 64);
 }
@@ -208,7 +224,10 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
             sset_item.insert(sset_item.end(), s.begin(), s.end());
             sset_off[i + 1] = (int64_t)sset_item.size();
             e->steps_per_epoch += (int64_t)sv[i].size();  // num_pos_trans
-            if (!s.empty() && (int)s.size() != I) elig.push_back(i);  // MC.cpp:84
+            // MC.cpp:84; an engine that holds a share of the users samples the same share of the source items (its sampler
+            // is driven by items, MC.cpp:80-89, so this is how N engines split an epoch's transitions)
+            const int64_t ib = (int64_t)I * ub / std::max(1, U), ie = (int64_t)I * ue / std::max(1, U);
+            if (!s.empty() && (int)s.size() != I && i >= ib && i < ie) elig.push_back(i);
         }
     } else {
         for (int u = ub; u < ue; u++) {
@@ -260,14 +279,23 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     // ---- device state
     DevModel& m = e->dm;
     memset(&m, 0, sizeof m);
+    m.user_begin = ub; m.user_end = ue;
     m.model = d->model; m.U = U; m.I = I; m.K = e->desc.K; m.KK = e->desc.KK; m.L = L;
     m.lambda = d->lambda; m.bias_reg = d->bias_reg; m.relation_reg = d->relation_reg; m.alpha = d->alpha;
     m.df = (double)e->desc.dataset_factor;
     int rc = 0;
 #define UP(vec, field) if (!rc) rc = upload(e, vec, &m.field)
-    UP(seq_off, seq_off); UP(seq_item, seq_item); UP(test_item, test_item); UP(val_item, val_item);
-    UP(clk_off, clk_off); UP(clk_item, clk_item); UP(first_occ, first_occ); UP(elig, elig); UP(eval_users, eval_users);
-    UP(train_count, train_count); UP(eta, eta); UP(owner_rec, owner_rec);
+    // Per-user data is resident for the engine's own users only (the offsets, 16 bytes per user, are kept whole):
+    // sequences, click sets, first-occurrence flags, sampling records, REBUS paths.  MC's sampling records are per item.
+#define UPR(vec, first, count, field) if (!rc) rc = upload_range(e, vec, (int64_t)(first), (int64_t)(count), &m.field)
+    UP(seq_off, seq_off); UP(test_item, test_item); UP(val_item, val_item); UP(clk_off, clk_off);
+    UPR(seq_item, seq_off[ub], seq_off[ue] - seq_off[ub], seq_item);
+    UPR(first_occ, seq_off[ub], seq_off[ue] - seq_off[ub], first_occ);
+    UPR(clk_item, clk_off[ub], clk_off[ue] - clk_off[ub], clk_item);
+    UP(elig, elig); UP(eval_users, eval_users);
+    UP(train_count, train_count); UP(eta, eta);
+    if (d->model == REC_MC) { UP(owner_rec, owner_rec); }
+    else { UPR(owner_rec, (int64_t)ub * 16, (int64_t)(ue - ub) * 16, owner_rec); }
     if (d->model == REC_MC) { UP(succ_off, succ_off); UP(succ_item, succ_item); UP(sset_off, sset_off); UP(sset_item, sset_item); }
     if (d->model == REC_REBUS && !rc) {
         const int64_t nctx = E + 2 * (int64_t)U;
@@ -275,9 +303,12 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
         std::vector<int32_t> pi(c->path_item, c->path_item + po[nctx]);
         for (int64_t x = 0; x < nctx && !rc; x++)
             if (po[x + 1] - po[x] > L) { rec_set_error("a matched path is longer than L"); rc = -1; }
-        UP(po, path_off); UP(pi, path_item);
+        // contexts of user u: [seq_off[u] + 2u, seq_off[u+1] + 2(u+1))
+        const int64_t c0 = seq_off[ub] + 2 * (int64_t)ub, c1 = seq_off[ue] + 2 * (int64_t)ue;
+        UPR(po, c0, c1 - c0 + 1, path_off); UPR(pi, po[c0], po[c1] - po[c0], path_item);
     }
 #undef UP
+#undef UPR
     m.n_elig = (int)elig.size(); m.n_eval = (int)eval_users.size(); m.n_ev = 0;
     m.elig_identity = 1;
     for (size_t i = 0; i < elig.size() && m.elig_identity; i++) if (elig[i] != (int32_t)i) m.elig_identity = 0;
@@ -292,7 +323,9 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     }
     (void)hipMemset(e->W, 0, e->dev_elems * e->elem_size);
     (void)hipMemset(e->bestW, 0, e->dev_elems * e->elem_size);
-    for (size_t t = 0; t < e->tables.size(); t++) m.tab[t] = (char*)e->W + e->tables[t].dev_off * e->elem_size;
+    // a table's base is where its row 0 would be: kernels index with global row numbers
+    for (size_t t = 0; t < e->tables.size(); t++)
+        m.tab[t] = (char*)e->W + (e->tables[t].dev_off - e->tables[t].row0 * e->tables[t].cols) * e->elem_size;
     void* g = nullptr;
     if (hipMalloc(&g, 8 * (REC_MAX_K + 2 * REC_MAX_L + 8)) != hipSuccess) { rec_set_error("hipMalloc failed"); return fail(-2); }
     e->owned.push_back(g); (void)hipMemset(g, 0, 8 * (REC_MAX_K + 2 * REC_MAX_L + 8));
@@ -412,10 +445,11 @@ extern "C" int rec_params_upload(rec_engine* e, const double* W, int64_t nw)
     ENG_HIP(hipSetDevice(e->desc.device));
     if (int rc = ensure_stage(e, std::min<int64_t>(STAGE_ELEMS, std::max<int64_t>(nw, 1)))) return rc;
     for (auto& t : e->tables) {
-        const int64_t n = t.rows * t.cols;
+        // the resident rows of the table (a user table of a sharded engine: its own users' rows; the others are ignored)
+        const int64_t n = t.nrows * t.cols, h0 = t.host_off + t.row0 * t.cols;
         for (int64_t o = 0; o < n; o += e->stage_elems) {
             const int64_t len = std::min(e->stage_elems, n - o);
-            ENG_HIP(hipMemcpyAsync(e->stage, W + t.host_off + o, sizeof(double) * len, hipMemcpyHostToDevice, e->st));
+            ENG_HIP(hipMemcpyAsync(e->stage, W + h0 + o, sizeof(double) * len, hipMemcpyHostToDevice, e->st));
             if (int rc = launch_convert_in(e->stage, (char*)e->W + (t.dev_off + o) * e->elem_size, len, e->desc.precision, e->st)) return rc;
             ENG_HIP(hipStreamSynchronize(e->st));
         }
@@ -430,11 +464,12 @@ extern "C" int rec_params_download(rec_engine* e, double* W, int64_t nw)
     ENG_HIP(hipSetDevice(e->desc.device));
     if (int rc = ensure_stage(e, std::min<int64_t>(STAGE_ELEMS, std::max<int64_t>(nw, 1)))) return rc;
     for (auto& t : e->tables) {
-        const int64_t n = t.rows * t.cols;
+        // the resident rows only: rows of other engines' users keep whatever W holds there
+        const int64_t n = t.nrows * t.cols, h0 = t.host_off + t.row0 * t.cols;
         for (int64_t o = 0; o < n; o += e->stage_elems) {
             const int64_t len = std::min(e->stage_elems, n - o);
             if (int rc = launch_convert_out((char*)e->W + (t.dev_off + o) * e->elem_size, e->stage, len, e->desc.precision, e->st)) return rc;
-            ENG_HIP(hipMemcpyAsync(W + t.host_off + o, e->stage, sizeof(double) * len, hipMemcpyDeviceToHost, e->st));
+            ENG_HIP(hipMemcpyAsync(W + h0 + o, e->stage, sizeof(double) * len, hipMemcpyDeviceToHost, e->st));
             ENG_HIP(hipStreamSynchronize(e->st));
         }
     }
@@ -449,10 +484,13 @@ extern "C" int rec_params_read(rec_engine* e, int64_t first, int64_t n, double* 
     ENG_HIP(hipStreamSynchronize(e->st));
     if (int rc = ensure_stage(e, std::min<int64_t>(STAGE_ELEMS, std::max<int64_t>(e->nw, 1)))) return rc;
     for (auto& t : e->tables) {
-        const int64_t a = std::max(first, t.host_off), b = std::min(first + n, t.host_off + t.rows * t.cols);
+        const int64_t h0 = t.host_off + t.row0 * t.cols;   // first resident element of the table in the flat vector
+        if (first < h0 && first + n > t.host_off && t.row0 > 0) { rec_set_error("parameter range holds rows of users that are not resident in this engine"); return -1; }
+        if (first + n > h0 + t.nrows * t.cols && first < t.host_off + t.rows * t.cols && t.nrows != t.rows) { rec_set_error("parameter range holds rows of users that are not resident in this engine"); return -1; }
+        const int64_t a = std::max(first, h0), b = std::min(first + n, h0 + t.nrows * t.cols);
         for (int64_t o = a; o < b; o += e->stage_elems) {
             const int64_t len = std::min(e->stage_elems, b - o);
-            if (int rc = launch_convert_out((char*)e->W + (t.dev_off + (o - t.host_off)) * e->elem_size, e->stage, len, e->desc.precision, e->st)) return rc;
+            if (int rc = launch_convert_out((char*)e->W + (t.dev_off + (o - h0)) * e->elem_size, e->stage, len, e->desc.precision, e->st)) return rc;
             ENG_HIP(hipMemcpyAsync(out + (o - first), e->stage, sizeof(double) * len, hipMemcpyDeviceToHost, e->st));
             ENG_HIP(hipStreamSynchronize(e->st));
         }
@@ -516,7 +554,12 @@ static int ensure_events(rec_engine* e)
     std::vector<int64_t> off(n_owner + 1);
     ENG_HIP(hipMemcpy(off.data(), mc ? m.succ_off : m.seq_off, sizeof(int64_t) * off.size(), hipMemcpyDeviceToHost));
     std::vector<int32_t> item(off[n_owner]);
-    ENG_HIP(hipMemcpy(item.data(), mc ? m.succ_item : m.seq_item, sizeof(int32_t) * item.size(), hipMemcpyDeviceToHost));
+    if (mc) ENG_HIP(hipMemcpy(item.data(), m.succ_item, sizeof(int32_t) * item.size(), hipMemcpyDeviceToHost));
+    else {
+        // only the sequences of the engine's own users are resident (and only they are eligible)
+        const int64_t a = off[e->desc.user_begin], b = off[e->desc.user_end];
+        if (b > a) ENG_HIP(hipMemcpy(item.data() + a, m.seq_item + a, sizeof(int32_t) * (size_t)(b - a), hipMemcpyDeviceToHost));
+    }
     auto n_events = [&](int o) -> int64_t { return (mc || bpr) ? off[o + 1] - off[o] : off[o + 1] - off[o] - 1; };
     auto event_of = [&](int o, int64_t x) -> int4 {
         if (mc || bpr) return make_int4(o, 0, item[off[o] + x], 0);
@@ -671,17 +714,19 @@ static int ev_end(rec_engine* e, int which, hipEvent_t a, hipEvent_t b)
 static int check_tuples(const rec_engine* e, const int32_t* t, int64_t n)
 {
     // operands must fit the tables before a kernel dereferences them
-    const int U = e->U, I = e->I; const int model = e->desc.model;
+    const int I = e->I; const int model = e->desc.model;
+    // users: only this engine's own (the rows and sequences of the others are not resident)
+    const int U0 = e->desc.user_begin, U = e->desc.user_end;
     for (int64_t i = 0; i < n; i++) {
         const int32_t a = t[4 * i], b = t[4 * i + 1], c = t[4 * i + 2], d = t[4 * i + 3];
         bool ok = true;
         switch (model) {
-        case REC_BPRMF: ok = a >= 0 && a < U && b >= 0 && b < I && c >= 0 && c < I; break;
+        case REC_BPRMF: ok = a >= U0 && a < U && b >= 0 && b < I && c >= 0 && c < I; break;
         case REC_MC: ok = a >= 0 && a < I && b >= 0 && b < I && c >= 0 && c < I; break;
-        case REC_FOSSIL: case REC_REBUS: ok = a >= 0 && a < U && c >= 0 && c < I; break;   // the position b is checked by the caller
-        default: ok = a >= 0 && a < U && b >= 0 && b < I && c >= 0 && c < I && d >= 0 && d < I; break;
+        case REC_FOSSIL: case REC_REBUS: ok = a >= U0 && a < U && c >= 0 && c < I; break;   // the position b is checked by the caller
+        default: ok = a >= U0 && a < U && b >= 0 && b < I && c >= 0 && c < I && d >= 0 && d < I; break;
         }
-        if (!ok) { rec_set_error("tuple " + std::to_string(i) + " is out of range"); return -1; }
+        if (!ok) { rec_set_error("tuple " + std::to_string(i) + " is out of range (or names a user of another engine)"); return -1; }
     }
     return 0;
 }
@@ -951,7 +996,7 @@ extern "C" int rec_eval_topk(rec_engine* e, const int32_t* users, int32_t n_user
     std::vector<int32_t> test(e->U);
     ENG_HIP(hipMemcpy(test.data(), e->dm.test_item, sizeof(int32_t) * e->U, hipMemcpyDeviceToHost));
     for (int i = 0; i < n_users; i++)
-        if (users[i] < 0 || users[i] >= e->U || test[users[i]] < 0) { rec_set_error("user " + std::to_string(users[i]) + " has no validation / test item"); return -1; }
+        if (users[i] < e->desc.user_begin || users[i] >= e->desc.user_end || test[users[i]] < 0) { rec_set_error("user " + std::to_string(users[i]) + " has no validation / test item"); return -1; }
     return eval_topk(e->dm, e->desc.precision, users, n_users, k, items_out, scores_out, e->st);
 }
 
@@ -960,7 +1005,7 @@ extern "C" int rec_num_tables(const rec_engine* e) { return e ? (int)e->tables.s
 extern "C" int rec_table_info(const rec_engine* e, int t, void** dev_ptr, int64_t* rows, int64_t* cols, int* is_user_table)
 {
     if (!e || t < 0 || t >= (int)e->tables.size()) { rec_set_error("no such table"); return -1; }
-    if (dev_ptr) *dev_ptr = (char*)e->W + e->tables[t].dev_off * e->elem_size;
+    if (dev_ptr) *dev_ptr = (char*)e->W + (e->tables[t].dev_off - e->tables[t].row0 * e->tables[t].cols) * e->elem_size;
     if (rows) *rows = e->tables[t].rows;
     if (cols) *cols = e->tables[t].cols;
     if (is_user_table) *is_user_table = e->tables[t].is_user;

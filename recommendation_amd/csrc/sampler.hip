@@ -436,14 +436,16 @@ int launch_convert_out(const void* src, double* dst, int64_t n, int precision, h
 // ------------------------------------------------------------------ parameter initialisation
 // v = lo + (hi - lo) * uniform[0,1), one Philox call per 4 values
 template <class T>
-__global__ void fill_uniform_kernel(T* __restrict__ dst, int64_t n, double lo, double hi, uint64_t seed, uint32_t stream)
+// elements [first, last) of the table whose element 0 is (or would be) at dst: a value depends only on its position in
+// the whole table, so an engine that holds a range of the rows gets the values the whole table would have there
+__global__ void fill_uniform_kernel(T* __restrict__ dst, int64_t first, int64_t last, double lo, double hi, uint64_t seed, uint32_t stream)
 {
     const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q * 4 < n; q += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t q = first / 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q * 4 < last; q += (int64_t)gridDim.x * blockDim.x) {
         const uint4 r = philox4x32(make_uint4((uint32_t)q, (uint32_t)(q >> 32), stream, 0u), key);
         const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
         for (int j = 0; j < 4; j++)
-            if (q * 4 + j < n) dst[q * 4 + j] = (T)(lo + (hi - lo) * ((double)rr[j] * (1.0 / 4294967296.0)));
+            if (q * 4 + j >= first && q * 4 + j < last) dst[q * 4 + j] = (T)(lo + (hi - lo) * ((double)rr[j] * (1.0 / 4294967296.0)));
     }
 }
 
@@ -464,35 +466,40 @@ __global__ void unit_ball_rows_kernel(T* __restrict__ tab, int64_t rows, int K)
 template <class T>
 static int param_init(const DevModel& m, uint64_t seed, hipStream_t st)
 {
-    const int64_t U = m.U, I = m.I, K = m.K, KK = m.KK, L = m.L;
+    const int64_t I = m.I, K = m.K, KK = m.KK, L = m.L;
     auto fill = [&](int t, int64_t n, double lo, double hi) {
-        if (n > 0) hipLaunchKernelGGL(fill_uniform_kernel<T>, dim3(grid_for((n + 3) / 4)), dim3(256), 0, st, (T*)m.tab[t], n, lo, hi, seed, (uint32_t)t);
+        if (n > 0) hipLaunchKernelGGL(fill_uniform_kernel<T>, dim3(grid_for((n + 3) / 4)), dim3(256), 0, st, (T*)m.tab[t], (int64_t)0, n, lo, hi, seed, (uint32_t)t);
+    };
+    // a table indexed by user: the rows of the engine's own users
+    auto fill_users = [&](int t, int64_t cols, double lo, double hi) {
+        const int64_t a = (int64_t)m.user_begin * cols, b = (int64_t)m.user_end * cols;
+        if (b > a) hipLaunchKernelGGL(fill_uniform_kernel<T>, dim3(grid_for((b - a + 3) / 4 + 1)), dim3(256), 0, st, (T*)m.tab[t], a, b, lo, hi, seed, (uint32_t)t);
     };
     auto ball = [&](int t, int64_t rows) {
         hipLaunchKernelGGL(unit_ball_rows_kernel<T>, dim3(grid_for(rows * 64)), dim3(256), 0, st, (T*)m.tab[t], rows, (int)K);
     };
     switch (m.model) {
     case REC_BPRMF:  // BPRMF.cpp:11-21
-        fill(BPRMF_BETA, I, 0, 0); fill(BPRMF_GU, U * K, 0, 1); fill(BPRMF_GI, I * K, 0, 1); break;
+        fill(BPRMF_BETA, I, 0, 0); fill_users(BPRMF_GU, K, 0, 1); fill(BPRMF_GI, I * K, 0, 1); break;
     case REC_MC:     // MC.cpp:30-32
         fill(MC_GI, I * K, 0, 1); fill(MC_ETA, I * K, 0, 1); break;
     case REC_FPMC:   // FPMC.cpp:11-13
-        fill(FPMC_GU, U * K, 0, 1); fill(FPMC_GI, I * K, 0, 1); fill(FPMC_KAPPA, I * KK, 0, 1); fill(FPMC_ETA, I * KK, 0, 1); break;
+        fill_users(FPMC_GU, K, 0, 1); fill(FPMC_GI, I * K, 0, 1); fill(FPMC_KAPPA, I * KK, 0, 1); fill(FPMC_ETA, I * KK, 0, 1); break;
     case REC_PRME:   // PRME.cpp:11-13
-        fill(PRME_GU, U * K, 0, 1); fill(PRME_GI, I * K, 0, 1); fill(PRME_ETA, I * KK, 0, 1); break;
+        fill_users(PRME_GU, K, 0, 1); fill(PRME_GI, I * K, 0, 1); fill(PRME_ETA, I * KK, 0, 1); break;
     case REC_HRM_AVG: case REC_HRM_MAX:  // HRM_avg.cpp:15-17
-        fill(HRM_U, U * K, -1.0 / K, 1.0 / K); fill(HRM_V, I * K, -1.0 / K, 1.0 / K); break;
+        fill_users(HRM_U, K, -1.0 / K, 1.0 / K); fill(HRM_V, I * K, -1.0 / K, 1.0 / K); break;
     case REC_TRANSREC: case REC_TRANSREC_L1: {  // TransRec.cpp:14-30
         const double range = 6.0 / sqrt((double)K);
-        fill(TR_BETA, I, 0, 0); fill(TR_H, I * K, range, -range); fill(TR_R, U * K, 0, 0); fill(TR_r, K, range, -range);
+        fill(TR_BETA, I, 0, 0); fill(TR_H, I * K, range, -range); fill_users(TR_R, K, 0, 0); fill(TR_r, K, range, -range);
         ball(TR_H, I); ball(TR_r, 1);
         break;
     }
     case REC_FOSSIL_SIMPLE:  // FossilSimple.cpp:11-17
-        fill(FS_ALPHA, 1, -1e-6, 1e-6); fill(FS_ALPHA_U, U, -1e-6, 1e-6); fill(FS_BETA, I, 0, 0);
+        fill(FS_ALPHA, 1, -1e-6, 1e-6); fill_users(FS_ALPHA_U, 1, -1e-6, 1e-6); fill(FS_BETA, I, 0, 0);
         fill(FS_UI, I * K, -1e-6, 1e-6); fill(FS_V, I * K, -1e-6, 1e-6); break;
     case REC_FOSSIL:         // Fossil.cpp:11-13
-        fill(FO_BETA, I, -1e-6, 1e-6); fill(FO_WT, L, -1e-6, 1e-6); fill(FO_WTU, U * L, -1e-6, 1e-6);
+        fill(FO_BETA, I, -1e-6, 1e-6); fill(FO_WT, L, -1e-6, 1e-6); fill_users(FO_WTU, L, -1e-6, 1e-6);
         fill(FO_UI, I * K, -1e-6, 1e-6); fill(FO_V, I * K, -1e-6, 1e-6); break;
     case REC_REBUS:          // REBUS.cpp:102-104
         fill(RB_BETA, I + 1, 0, 1); fill(RB_P, (I + 1) * K, 0, 1); break;

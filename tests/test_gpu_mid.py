@@ -56,3 +56,50 @@ def test_shared_negatives_follow_the_reference(model):
 @pytest.mark.parametrize("model", HISTORY)
 def test_history_pairs_follow_the_reference(model):
     _check(model, HISTORY_PAIRS)
+
+
+@pytest.mark.parametrize("model,world", [("BPRMF", 2), ("BPRMF", 4), ("FPMC", 4), ("TransRec", 2)])
+def test_user_sharded_training_follows_the_reference(model, world):
+    """N user shards (in-process emulation of N ranks on one GPU, recommendation_amd.sharded.ShardGroup: same arithmetic
+    as N processes with an all-reduce) with the default exchange period: same bounds against the reference's
+    trajectories as the single-engine runs.  The gathered parameter vector (item tables + every shard's user rows), loaded
+    into one engine, scores exactly like the shards did."""
+    import torch
+    import recommendation_amd as ra
+    from oracle import oracle_py as orc
+    from recommendation_amd.capi import F32
+    from recommendation_amd.sharded import ShardGroup
+    from tests.converge_util import mid_corpus
+    ref = [r for r in REF if r["model"] == model]
+    r0 = ref[0]
+    co, ci = mid_corpus()
+    seq_off, seq_item, test, val = orc.split(co, ci)
+    I, U = int(ci.max()) + 1, len(seq_off) - 1
+    kw = dict(K=r0["K"], L=r0["L"], lam=r0["lam"], bias_reg=r0["bias_reg"], relation_reg=r0["relation_reg"], alpha=r0["alpha"], precision=F32)
+
+    def make(ub, ue):
+        return ra.Engine(model, I, seq_off, seq_item, test, val, user_begin=ub, user_end=ue, **kw)
+
+    g = ShardGroup(make, U, world, torch.device("cuda", 0))
+    assert g.rounds == -(-g.engines[0].steps_per_epoch // (2 * I))
+    g.init_params(0)
+    best = None
+    for it in range(1, r0["epochs"] + 1):
+        g.epoch(0.05, 0, it)
+        if it % r0["every"] == 0:
+            m = g.metrics()
+            if best is None or m[0] > best[0]:
+                best = m
+    auc_ref = np.mean([r["auc_test_at_best"] for r in ref]); hit_ref = [r["hit50_test_at_best"] for r in ref]
+    msg = (model, world, best, auc_ref, np.mean(hit_ref))
+    assert abs(best[1] - auc_ref) <= 0.005 + 0.002, msg      # one engine seed against the mean of three reference seeds
+    assert abs(best[3] - np.mean(hit_ref)) <= max(0.008, max(hit_ref) - min(hit_ref)), msg
+    # what a sharded run saves: the item tables of any replica + the user rows of their owners
+    last = g.metrics()
+    W = g.gather_params()
+    g.close()
+    one = ra.Engine(model, I, seq_off, seq_item, test, val, **kw)
+    one.upload(W)
+    m1, _, _ = one.eval(want_counts=False)
+    assert np.allclose(m1.as_array()[:6], last[:6], rtol=0, atol=1e-12)
+    one.close()
