@@ -9,6 +9,7 @@
 #define REC_MAX_EPL 4   // elements per lane: K <= 64 * REC_MAX_EPL
 #define REC_MAX_K (64 * REC_MAX_EPL)
 #define REC_MAX_L 32
+#define REC_HOT_SLOTS 32   // hot items that get an accumulator of their own in every workgroup of the wide owner kernel
 
 // Everything a kernel needs to know about the model and the corpus; passed by value.
 struct DevModel {
@@ -50,7 +51,12 @@ struct DevModel {
     const float* ev_alias_p;            // [n_ev]
     const int32_t* ev_alias_i;          // [n_ev] slot inside the item's range
     const int32_t* train_count;         // [I] occurrences of each item in the training sequences (MostPopular)
-    const uint8_t* hot;                 // [I+1] 1 = item whose rows are not scattered with atomics (see rec_set_option "hot_count")
+    // [I+1] 0 = ordinary item; otherwise a "hot" item (see rec_set_option "hot_count"): its rows are not scattered with
+    // per-tuple atomics.  1 .. REC_HOT_SLOTS: the item has accumulator slot (value - 1) in the owner mode of the wide
+    // kernel (hot_items[slot] = the item); 255: hot without a slot.
+    const uint8_t* hot;
+    const int32_t* hot_items;           // [REC_HOT_SLOTS] item of each accumulator slot (-1: unused)
+    int n_hot_slots;
 };
 
 // table indices, in the flat order of each model's getParametersFromVector / parametersToFlatVector
@@ -91,7 +97,7 @@ int launch_sgd_owner(const DevModel& m, int precision, const int4* partitioned, 
 // The wide form of the Hogwild kernel (sgd_wide.hip): f32 tables, K and KK multiples of 4; qoff as for launch_sgd_owner
 // (nullptr: plain mode on the tuples as they come)
 bool sgd_wide_supported(const DevModel& m, int precision);
-int launch_sgd_wide(const DevModel& m, const int4* tuples, const int64_t* qoff, int64_t n, double lr, int atomic, int flush_at, hipStream_t st);
+int launch_sgd_wide(const DevModel& m, const int4* tuples, const int64_t* qoff, int64_t n, double lr, int atomic, int flush_at, int hot_flush, hipStream_t st);
 // Stable-by-block partition of n tuples by (component `field`) / slice_rows into `slices` ranges of dst; qoff[slices+1]
 // (device) receives the range starts.  scratch: partition_scratch_bytes(n, slices).
 size_t partition_scratch_bytes(int64_t n, int slices);
@@ -132,7 +138,6 @@ size_t event_scratch_bytes(int64_t n_ev);
 int launch_event_sampler(const DevModel& m, int4* tuples, int64_t cap, int64_t n_expected, int64_t first_step, uint64_t chunk_no,
                          uint64_t seed, uint64_t epoch, void* scratch, int64_t* n_out_dev, hipStream_t st);
 
-int launch_mark_hot(const DevModel& m, uint8_t* hot, int64_t min_count, hipStream_t st);
 
 // Evaluation of the users in m.eval_users against the whole catalog (n_subset = 0) or against the n_subset items
 // listed in subset_host (host memory, repetitions allowed: every occurrence is one scored candidate).

@@ -39,6 +39,7 @@ struct rec_engine {
     hipEvent_t ev_sampled[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
     bool consumed_valid[2] = {false, false};
     std::vector<void*> owned;
+    std::vector<int32_t> train_count_host;  // occurrences of every item in the training sequences (hot-item selection)
     std::vector<int64_t> seq_off_host;  // host copy of the training sequence offsets (replay argument checks)
     // options
     int64_t chunk = 1 << 26;
@@ -57,6 +58,7 @@ struct rec_engine {
     int wide = 1;        // 1: the wide form of the Hogwild kernel (sgd_wide.hip) where it applies
     int owner = 0;       // 1: launches of >= owner_min tuples are partitioned by the negative's slice of the catalog and applied in owner mode
     int owner_flush = 8; // additions after which an LDS accumulator row is moved to memory
+    int hot_flush = 64;  // the same for the accumulators of the hot items (per workgroup and table)
     int64_t owner_min = 1 << 20;
     void* part_scratch = nullptr; size_t part_scratch_bytes = 0;
     int64_t* qoff_dev = nullptr;
@@ -293,6 +295,7 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     UPR(first_occ, seq_off[ub], seq_off[ue] - seq_off[ub], first_occ);
     UPR(clk_item, clk_off[ub], clk_off[ue] - clk_off[ub], clk_item);
     UP(elig, elig); UP(eval_users, eval_users);
+    e->train_count_host = train_count;
     UP(train_count, train_count); UP(eta, eta);
     if (d->model == REC_MC) { UP(owner_rec, owner_rec); }
     else { UPR(owner_rec, (int64_t)ub * 16, (int64_t)(ue - ub) * 16, owner_rec); }
@@ -338,6 +341,10 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     if (hipMalloc(&hot, I + 64) != hipSuccess) { rec_set_error("hipMalloc failed"); return fail(-2); }
     e->owned.push_back(hot); (void)hipMemset(hot, 0, I + 64);
     m.hot = (const uint8_t*)hot;
+    void* hot_items = nullptr;
+    if (hipMalloc(&hot_items, sizeof(int32_t) * REC_HOT_SLOTS) != hipSuccess) { rec_set_error("hipMalloc failed"); return fail(-2); }
+    e->owned.push_back(hot_items); (void)hipMemset(hot_items, 0xff, sizeof(int32_t) * REC_HOT_SLOTS);
+    m.hot_items = (const int32_t*)hot_items; m.n_hot_slots = 0;
     // All tuples of one launch may be computed from the same parameter values.  With a small catalog a launch is
     // therefore kept short enough that an item row receives about two updates per launch on average; with a
     // large catalog the number of tuples the chip has in flight (tens of thousands) is below that bound anyway.
@@ -383,9 +390,9 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     // by the arithmetic of its projections.  ("share_negative" 2, pairs of steps drawing one negative, is the older
     // way to the same saving; it changes the joint distribution of consecutive steps and stays an option.)
     const bool transrec = d->model == REC_TRANSREC || d->model == REC_TRANSREC_L1;
-    // (f32 tables only: the f64 form of the kernel is issue-bound and loses more to the accumulator traffic than it saves)
-    e->owner = (!history_model(d->model) && !transrec && sgd_owner_supported(d->model) && d->precision == REC_F32 &&
-                e->steps_per_epoch >= (1 << 22)) ? 1 : 0;
+    // (where the wide kernel applies - f32 tables, K a multiple of 4: only that kernel also keeps the hot items' sums in
+    // LDS; the one-dword-per-lane form is issue-bound and gains little)
+    e->owner = (!history_model(d->model) && !transrec && sgd_wide_supported(e->dm, d->precision) && e->steps_per_epoch >= (1 << 22)) ? 1 : 0;
     e->neg_share = 1;
     *out = e;
     return 0;
@@ -673,7 +680,7 @@ static int launch_update(rec_engine* e, const int4* tuples, int64_t n, double lr
             int rc = launch_partition_by_slice(tuples + o, dst, len, sgd_owner_neg_field(model), sgd_owner_slice_rows(e->dm), slices,
                                                e->part_scratch, e->qoff_dev, e->st);
             if (e->profile) { ENG_HIP(hipEventRecord(pb, e->st)); e->pending[3].push_back({pa, pb}); }
-            if (!rc) rc = use_wide ? launch_sgd_wide(e->dm, dst, e->qoff_dev, len, lr, e->atomic, e->owner_flush, e->st)
+            if (!rc) rc = use_wide ? launch_sgd_wide(e->dm, dst, e->qoff_dev, len, lr, e->atomic, e->owner_flush, e->hot_flush, e->st)
                                    : launch_sgd_owner(e->dm, e->desc.precision, dst, e->qoff_dev, len, lr, e->atomic, e->owner_flush, e->st);
             if (rc) return rc;
             if (global_row) {
@@ -683,7 +690,7 @@ static int launch_update(rec_engine* e, const int4* tuples, int64_t n, double lr
         }
         int rc = history ? launch_sgd_history(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic, e->stale_window, user_batch, e->st)
                  : ((grouped || e->group == 1) && sgd_runs_supported(model)) ? launch_sgd_runs(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic, e->run_segment, e->run_policy, e->st)
-                 : use_wide ? launch_sgd_wide(e->dm, tuples + o, nullptr, len, lr, e->atomic, 1, e->st)
+                 : use_wide ? launch_sgd_wide(e->dm, tuples + o, nullptr, len, lr, e->atomic, 1, 1, e->st)
                          : launch_sgd_hogwild(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic | ((e->neg_share >= 4 ? 2 : (e->neg_share == 2 || e->pos_share == 2) ? 1 : 0) << 16), e->st);
         if (rc) return rc;
         if (global_row) {
@@ -1055,14 +1062,31 @@ extern "C" int rec_set_option(rec_engine* e, const char* name, int64_t value)
     else if (s == "wide") { if (value != 0 && value != 1) { rec_set_error("wide must be 0 or 1"); return -1; } e->wide = (int)value; }
     else if (s == "owner_neg") { if (value != 0 && value != 1) { rec_set_error("owner_neg must be 0 or 1"); return -1; } e->owner = (int)value; }
     else if (s == "owner_flush") { if (value < 1 || value > 65536) { rec_set_error("owner_flush must be in 1..65536"); return -1; } e->owner_flush = (int)value; }
+    else if (s == "hot_flush") { if (value < 1 || value > 65536) { rec_set_error("hot_flush must be in 1..65536"); return -1; } e->hot_flush = (int)value; }
     else if (s == "owner_min") { if (value < 1) { rec_set_error("owner_min must be positive"); return -1; } e->owner_min = value; }
     else if (s == "run_segment") { if (value < 0) { rec_set_error("run_segment must be >= 0"); return -1; } e->run_segment = value; }
     else if (s == "group_by_item") { if (value < 0 || value > 3) { rec_set_error("group_by_item must be 0..3"); return -1; } e->group = (int)value; }
     else if (s == "hot_count") {
-        // items with at least `value` training occurrences are "hot" (0 = none)
+        // items with at least `value` training occurrences are "hot" (0 = none); the REC_HOT_SLOTS most frequent of them
+        // get an accumulator slot (flag = slot + 1), the others the flag 255
         ENG_HIP(hipSetDevice(e->desc.device));
-        if (int rc = launch_mark_hot(e->dm, (uint8_t*)e->dm.hot, value, e->st)) return rc;
         ENG_HIP(hipStreamSynchronize(e->st));
+        const int I = e->I;
+        std::vector<uint8_t> flags((size_t)I + 1, 0);
+        std::vector<int32_t> slots(REC_HOT_SLOTS, -1);
+        int n_slots = 0;
+        if (value > 0) {
+            std::vector<std::pair<int32_t, int32_t>> hot;   // (-count, item): most frequent first, ties by item id
+            for (int i = 0; i < I; i++) if (e->train_count_host[i] >= value) hot.push_back({-e->train_count_host[i], i});
+            std::sort(hot.begin(), hot.end());
+            for (size_t k = 0; k < hot.size(); k++) {
+                if ((int)k < REC_HOT_SLOTS) { flags[hot[k].second] = (uint8_t)(k + 1); slots[k] = hot[k].second; n_slots = (int)k + 1; }
+                else flags[hot[k].second] = 255;
+            }
+        }
+        ENG_HIP(hipMemcpy((void*)e->dm.hot, flags.data(), flags.size(), hipMemcpyHostToDevice));
+        ENG_HIP(hipMemcpy((void*)e->dm.hot_items, slots.data(), sizeof(int32_t) * REC_HOT_SLOTS, hipMemcpyHostToDevice));
+        e->dm.n_hot_slots = n_slots;
     }
     else { rec_set_error("unknown option " + s); return -1; }
     return 0;

@@ -513,17 +513,3 @@ int launch_param_init(const DevModel& m, int precision, uint64_t seed, hipStream
 {
     return precision == REC_F64 ? param_init<double>(m, seed, st) : param_init<float>(m, seed, st);
 }
-
-// ------------------------------------------------------------------ hot-item flags
-__global__ void mark_hot_kernel(const int32_t* __restrict__ count, uint8_t* __restrict__ hot, int I, int64_t min_count)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i <= I) hot[i] = (i < I && min_count > 0 && count[i] >= min_count) ? 1 : 0;
-}
-
-int launch_mark_hot(const DevModel& m, uint8_t* hot, int64_t min_count, hipStream_t st)
-{
-    hipLaunchKernelGGL(mark_hot_kernel, dim3((m.I + 256) / 256), dim3(256), 0, st, m.train_count, hot, m.I, min_count);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}

@@ -38,11 +38,20 @@ __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_ker
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
 
-    // dynamic LDS: [staging: 64 x 4 floats per wavefront][owner mode: accumulators [rows_res][acc_width], pend [rows_res]]
+    // dynamic LDS: [staging: 64 x 4 floats per wavefront][owner mode: accumulators [rows_res][acc_width], ...]
     extern __shared__ __align__(16) unsigned char wide_lds[];
     T* stage = (T*)wide_lds + (size_t)wave * 256;
     T* acc = (T*)wide_lds + (size_t)(blockDim.x >> 6) * 256;
-    unsigned* pend = (unsigned*)(acc + (size_t)ow.rows_res * ow.acc_width);
+    // owner mode: [hot_slots][hot_width] sums of this workgroup's deltas to the hot items' other rows (behind acc, so that
+    // both stay 16-byte aligned for the four-float accesses); then the counters: pend [rows_res] additions to an
+    // accumulator row since its last flush, hot_pend [hot_slots][tables] the same per hot item and table
+    constexpr int NSEG = HotSegs<MODEL>::N;
+    T* hot_acc = acc + (size_t)ow.rows_res * ow.acc_width;
+    unsigned* pend = (unsigned*)(hot_acc + (size_t)ow.hot_slots * ow.hot_width);
+    unsigned* hot_pend = pend + ow.rows_res;
+    // owner mode, models with item biases: [rows_res] this workgroup's pending additions to the bias of each resident item
+    // in the negative's role (plain stores of the tuples it applies at the same moment would overwrite each other)
+    T* acc_bias = (T*)(hot_pend + ow.hot_slots * NSEG);
     __shared__ int lds_next;
     const int slice_base = OWNER ? (int)blockIdx.x * ow.slice_rows : 0;
     if constexpr (OWNER) {
@@ -50,6 +59,9 @@ __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_ker
         tuples += q0; n = ow.qoff[blockIdx.x + 1] - q0;
         for (int i = threadIdx.x; i < ow.rows_res * ow.acc_width; i += blockDim.x) acc[i] = 0;
         for (int i = threadIdx.x; i < ow.rows_res; i += blockDim.x) pend[i] = 0;
+        for (int i = threadIdx.x; i < ow.hot_slots * ow.hot_width; i += blockDim.x) hot_acc[i] = 0;
+        for (int i = threadIdx.x; i < ow.hot_slots * NSEG; i += blockDim.x) hot_pend[i] = 0;
+        if constexpr (NB == 2) for (int i = threadIdx.x; i < ow.rows_res; i += blockDim.x) acc_bias[i] = 0;
         if (threadIdx.x == 0) lds_next = 0;
         __syncthreads();
     }
@@ -157,10 +169,14 @@ __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_ker
         int hfn; uint8_t bias_hot_n;
         load_rows(tn, vn, bn, hfn, bias_hot_n);
         T mine = 0;
+        int bias_slot = -1;   // owner mode: accumulator slot of the (negative's) bias this lane holds, -1: the bias lives in memory
 #pragma unroll
         for (int b = 0; b < B; b++) {
             const bool ok = tp[b].x >= 0;
             const int sl = slot_of(tp[b]);
+            if constexpr (OWNER && NB == 2) {
+                if (sl >= 0 && g == 2 * b + 1) { bias_slot = sl; bs += acc_bias[sl]; }
+            }
             T w[R][EPL], old[R][EPL];
 #pragma unroll
             for (int r = 0; r < R; r++) { w[r][0] = v[b][r].x; w[r][1] = v[b][r].y; w[r][2] = v[b][r].z; w[r][3] = v[b][r].w; }
@@ -178,22 +194,46 @@ __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_ker
                     }
                 }
             }
-            bool at[R];
+            // Rows of hot items are not scattered with per-tuple atomics: from all over the chip they would serialize on
+            // one address.  Plain mode: plain racy stores instead.  Owner mode: the negative's rows are summed in LDS whether
+            // hot or not (plain stores of the tuples one workgroup applies at the same moment would overwrite each other),
+            // and a hot item's other rows go to the workgroup's accumulator of that item: no update is lost, and memory
+            // sees one atomic row per hot_flush additions of a workgroup.
+            bool at[R]; int hs[R];   // hs: accumulator slot of the row's hot item (-1: none)
 #pragma unroll
             for (int r = 0; r < R; r++) {
+                const int flag = __shfl(hf, b * R + r, LPT);
+                hs[r] = (OWNER && hot_seg<MODEL>(r) >= 0 && flag >= 1 && flag <= ow.hot_slots) ? flag - 1 : -1;
+                // (owner mode: a hot item beyond the accumulator slots takes per-tuple atomics - its negative's sums arrive as
+                // atomics, and a plain store of old + delta would wipe them out)
+                at[r] = ((atomic >> r) & 1) && (OWNER || !flag);
+                if constexpr (OWNER) {
+                    if (hs[r] >= 0) {
+                        const int width = (hot_seg<MODEL>(r) > 0 && (MODEL == REC_FPMC || MODEL == REC_PRME)) ? m.KK : m.K;
+                        if (FULL || EPL * g < width) {
+                            const float4 a = *reinterpret_cast<const float4*>(hot_acc + (size_t)hs[r] * ow.hot_width + hot_seg_off<MODEL>(hot_seg<MODEL>(r), m.K, m.KK) + EPL * g);
+                            w[r][0] += a.x; w[r][1] += a.y; w[r][2] += a.z; w[r][3] += a.w;
+                        }
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < EPL; j++) old[r][j] = w[r][j];
-                at[r] = ((atomic >> r) & 1) && !__shfl(hf, b * R + r, LPT);
             }
             const T b0 = NB == 2 ? __shfl(bs, 2 * b, LPT) : (T)0, b1 = NB == 2 ? __shfl(bs, 2 * b + 1, LPT) : (T)0;
             const T deri = step<MODEL, T, LPT, EPL, 1>(m, lr, g, w, b0, b1, rg, racc, at);
             if ((g >> 1) == b) mine = deri;
+            // moves what a group has taken out of an LDS accumulator (x, zeros for groups that take nothing) to memory
+            auto stage_and_flush = [&](const float4& x, T* tab, int width, int rownum) {
+                *reinterpret_cast<float4*>(stage + EPL * lane) = x;
+                flush_stage(tab, width, rownum);
+            };
             bool accumulated = false;
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 int width; T* row = row_ptr<MODEL, T>(m, tp[b], r, width);
                 const bool act = ok && (FULL || EPL * g < width);
                 const bool to_acc = OWNER && owned_row<MODEL>(r) && sl >= 0 && at[r];
+                const bool to_hot = OWNER && hs[r] >= 0 && at[r] && ok;
                 if (to_acc) {
                     if (act) {
                         T* a = acc + (size_t)sl * ow.acc_width + owned_off<MODEL>(r, m.K) + EPL * g;
@@ -201,15 +241,36 @@ __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_ker
                         for (int j = 0; j < EPL; j++) unsafeAtomicAdd(a + j, w[r][j]);
                     }
                     accumulated = true;
+                } else if (to_hot) {
+                    if (act) {
+                        T* a = hot_acc + (size_t)hs[r] * ow.hot_width + hot_seg_off<MODEL>(hot_seg<MODEL>(r), m.K, m.KK) + EPL * g;
+#pragma unroll
+                        for (int j = 0; j < EPL; j++) unsafeAtomicAdd(a + j, w[r][j]);
+                    }
                 } else if (!at[r]) {
                     if (act) *reinterpret_cast<float4*>(row + EPL * g) = make_float4(old[r][0] + w[r][0], old[r][1] + w[r][1], old[r][2] + w[r][2], old[r][3] + w[r][3]);
                 }
-                // atomics: through the staging image, if any group of the wavefront needs them for this row
-                const bool wants = ok && at[r] && !to_acc;
-                if (__ballot(wants)) {
-                    *reinterpret_cast<float4*>(stage + EPL * lane) = make_float4(w[r][0], w[r][1], w[r][2], w[r][3]);
-                    flush_stage(row_table<MODEL, T>(m, r), width, wants ? row_number<MODEL>(tp[b], r) : -1);
+                if constexpr (OWNER) {
+                    if (hot_seg<MODEL>(r) >= 0) {
+                        // every hot_flush-th addition of this workgroup to the hot item's table moves the sum to memory
+                        bool fire0 = false;
+                        if (to_hot && g == 0) fire0 = atomicInc(hot_pend + hs[r] * NSEG + hot_seg<MODEL>(r), (unsigned)(ow.hot_flush - 1)) == (unsigned)(ow.hot_flush - 1);
+                        const unsigned long long fired = __ballot(fire0);
+                        if (fired) {
+                            const bool fire = (fired >> (lane & ~(LPT - 1))) & 1ull;
+                            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (fire && (FULL || EPL * g < width)) {
+                                T* a = hot_acc + (size_t)hs[r] * ow.hot_width + hot_seg_off<MODEL>(hot_seg<MODEL>(r), m.K, m.KK) + EPL * g;
+                                x = make_float4(lds_take(a), lds_take(a + 1), lds_take(a + 2), lds_take(a + 3));
+                            }
+                            stage_and_flush(x, row_table<MODEL, T>(m, r), width, fire ? row_number<MODEL>(tp[b], r) : -1);
+                        }
+                    }
                 }
+                // atomics: through the staging image, if any group of the wavefront needs them for this row
+                const bool wants = ok && at[r] && !to_acc && !to_hot;
+                if (__ballot(wants))
+                    stage_and_flush(make_float4(w[r][0], w[r][1], w[r][2], w[r][3]), row_table<MODEL, T>(m, r), width, wants ? row_number<MODEL>(tp[b], r) : -1);
             }
             if constexpr (OWNER) {
                 // every flush_at-th addition to an item moves its accumulated delta to memory: one atomic row for all of them
@@ -227,8 +288,10 @@ __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_ker
                             T* a = acc + (size_t)sl * ow.acc_width + owned_off<MODEL>(r, m.K) + EPL * g;
                             x = make_float4(lds_take(a), lds_take(a + 1), lds_take(a + 2), lds_take(a + 3));
                         }
-                        *reinterpret_cast<float4*>(stage + EPL * lane) = x;
-                        flush_stage(row_table<MODEL, T>(m, r), width, fire ? row_number<MODEL>(tp[b], r) : -1);
+                        stage_and_flush(x, row_table<MODEL, T>(m, r), width, fire ? row_number<MODEL>(tp[b], r) : -1);
+                    }
+                    if constexpr (NB == 2) {
+                        if (fire && g == 0) unsafeAtomicAdd(bias_ptr<MODEL, T>(m, tp[b], 1), lds_take(acc_bias + sl));
                     }
                 }
             }
@@ -238,7 +301,8 @@ __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_ker
             T* p = my_bias_ptr(tp);
             const T sgn = ((g & 1) == 0) == (MODEL == REC_BPRMF) ? (T)1 : (T)-1;
             const T delta = p ? lr * (sgn * mine - (T)m.bias_reg * bs) : (T)0;
-            if (p) scatter(p, delta, bs, ((atomic >> 8) & 1) && !bias_hot);
+            if (p && bias_slot >= 0) unsafeAtomicAdd(acc_bias + bias_slot, delta);
+            else if (p) scatter(p, delta, bs, ((atomic >> 8) & 1) && !bias_hot);
         }
         bs = bn; bias_hot = bias_hot_n; hf = hfn;
         b_p = b_n; b_n = b_nn;
@@ -267,6 +331,29 @@ __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_ker
                 *reinterpret_cast<float4*>(stage + EPL * lane) = x;
                 flush_stage(row_table<MODEL, T>(m, r), width, dirty ? slice_base + sl : -1);
             }
+            if constexpr (NB == 2) {
+                if (dirty && g == 0) unsafeAtomicAdd((T*)m.tab[MODEL == REC_BPRMF ? BPRMF_BETA : TR_BETA] + slice_base + sl, acc_bias[sl]);
+            }
+        }
+        // and the hot items' sums, one group per (slot, table)
+        for (int s0 = 0; s0 < ow.hot_slots * NSEG; s0 += groups) {
+            const int idx = s0 + gid;
+            const bool dirty = idx < ow.hot_slots * NSEG && hot_pend[idx] != 0;
+            if (!__ballot(dirty)) continue;
+            const int slot = idx / NSEG, seg = idx % NSEG;
+            const int item = dirty ? m.hot_items[slot] : -1;
+#pragma unroll
+            for (int sg = 0; sg < NSEG; sg++) {
+                // a wave-instruction of the staged scatter serves one table: the groups take turns by table
+                const bool mine_now = dirty && seg == sg;
+                if (!__ballot(mine_now)) continue;
+                const int rr = sg == 0 ? hot_seg_row<MODEL>(0) : sg == 1 ? hot_seg_row<MODEL>(1) : hot_seg_row<MODEL>(2);
+                const int width = (sg > 0 && (MODEL == REC_FPMC || MODEL == REC_PRME)) ? m.KK : m.K;
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (mine_now && (FULL || EPL * g < width)) x = *reinterpret_cast<const float4*>(hot_acc + (size_t)slot * ow.hot_width + hot_seg_off<MODEL>(sg, m.K, m.KK) + EPL * g);
+                *reinterpret_cast<float4*>(stage + EPL * lane) = x;
+                flush_stage(row_table<MODEL, T>(m, rr), width, mine_now ? item : -1);
+            }
         }
     }
 
@@ -287,18 +374,20 @@ __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_ker
 static size_t wide_owner_lds_budget() { return 160 * 1024 - 1024 - 256; }   // less the kernel's static LDS (TransRec's reduction row)
 
 template <int MODEL>
-static int wide_dispatch(const DevModel& m, const int4* tuples, int64_t n, double lr, int atomic, const int64_t* qoff, int flush_at, hipStream_t st)
+static int wide_dispatch(const DevModel& m, const int4* tuples, int64_t n, double lr, int atomic, const int64_t* qoff, int flush_at, int hot_flush, hipStream_t st)
 {
     const int Kmax = m.K > m.KK ? m.K : m.KK;
-    OwnerArgs ow = {nullptr, 0, 0, 0, 1};
+    OwnerArgs ow = {nullptr, 0, 0, 0, 1, 0, 0, 1};
     auto go = [&](auto kern, auto kern_owner, int lpt, int b) -> int {
         if (qoff) {
             const size_t stage_bytes = (size_t)(WIDE_OWNER_THREADS / 64) * 1024;
             ow.qoff = qoff; ow.slice_rows = (m.I + WIDE_SLICES - 1) / WIDE_SLICES; ow.flush_at = flush_at < 1 ? 1 : flush_at;
             ow.acc_width = (MODEL == REC_FPMC || MODEL == REC_PRME) ? m.K + m.KK : m.K;
-            const size_t per_row = (size_t)ow.acc_width * sizeof(float) + sizeof(unsigned);
-            ow.rows_res = (int)std::min<size_t>((size_t)ow.slice_rows, (wide_owner_lds_budget() - stage_bytes) / per_row);
-            const size_t lds = stage_bytes + (size_t)ow.rows_res * per_row;
+            ow.hot_slots = m.n_hot_slots; ow.hot_width = hot_width<MODEL>(m.K, m.KK); ow.hot_flush = hot_flush < 1 ? 1 : hot_flush;
+            const size_t hot_bytes = (size_t)ow.hot_slots * ((size_t)ow.hot_width * sizeof(float) + sizeof(unsigned) * HotSegs<MODEL>::N);
+            const size_t per_row = (size_t)ow.acc_width * sizeof(float) + sizeof(unsigned) + (Spec<MODEL>::NB == 2 ? sizeof(float) : 0);
+            ow.rows_res = (int)std::min<size_t>((size_t)ow.slice_rows, (wide_owner_lds_budget() - stage_bytes - hot_bytes) / per_row);
+            const size_t lds = stage_bytes + (size_t)ow.rows_res * per_row + hot_bytes;
             HIP_TRY(hipFuncSetAttribute((const void*)kern_owner, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern_owner, dim3(WIDE_SLICES), dim3(WIDE_OWNER_THREADS), lds, st, m, tuples, n, (float)lr, atomic, ow);
             return 0;
@@ -337,18 +426,18 @@ bool sgd_wide_supported(const DevModel& m, int precision)
 }
 
 // qoff == nullptr: plain mode on the tuples as they come; else owner mode on tuples partitioned by the negative's slice
-int launch_sgd_wide(const DevModel& m, const int4* tuples, const int64_t* qoff, int64_t n, double lr, int atomic, int flush_at, hipStream_t st)
+int launch_sgd_wide(const DevModel& m, const int4* tuples, const int64_t* qoff, int64_t n, double lr, int atomic, int flush_at, int hot_flush, hipStream_t st)
 {
     if (n <= 0) return 0;
     switch (m.model) {
-    case REC_BPRMF: return wide_dispatch<REC_BPRMF>(m, tuples, n, lr, atomic, qoff, flush_at, st);
-    case REC_MC: return wide_dispatch<REC_MC>(m, tuples, n, lr, atomic, qoff, flush_at, st);
-    case REC_FPMC: return wide_dispatch<REC_FPMC>(m, tuples, n, lr, atomic, qoff, flush_at, st);
-    case REC_PRME: return wide_dispatch<REC_PRME>(m, tuples, n, lr, atomic, qoff, flush_at, st);
-    case REC_HRM_AVG: return wide_dispatch<REC_HRM_AVG>(m, tuples, n, lr, atomic, qoff, flush_at, st);
-    case REC_HRM_MAX: return wide_dispatch<REC_HRM_MAX>(m, tuples, n, lr, atomic, qoff, flush_at, st);
-    case REC_TRANSREC: return wide_dispatch<REC_TRANSREC>(m, tuples, n, lr, atomic, qoff, flush_at, st);
-    case REC_TRANSREC_L1: return wide_dispatch<REC_TRANSREC_L1>(m, tuples, n, lr, atomic, qoff, flush_at, st);
+    case REC_BPRMF: return wide_dispatch<REC_BPRMF>(m, tuples, n, lr, atomic, qoff, flush_at, hot_flush, st);
+    case REC_MC: return wide_dispatch<REC_MC>(m, tuples, n, lr, atomic, qoff, flush_at, hot_flush, st);
+    case REC_FPMC: return wide_dispatch<REC_FPMC>(m, tuples, n, lr, atomic, qoff, flush_at, hot_flush, st);
+    case REC_PRME: return wide_dispatch<REC_PRME>(m, tuples, n, lr, atomic, qoff, flush_at, hot_flush, st);
+    case REC_HRM_AVG: return wide_dispatch<REC_HRM_AVG>(m, tuples, n, lr, atomic, qoff, flush_at, hot_flush, st);
+    case REC_HRM_MAX: return wide_dispatch<REC_HRM_MAX>(m, tuples, n, lr, atomic, qoff, flush_at, hot_flush, st);
+    case REC_TRANSREC: return wide_dispatch<REC_TRANSREC>(m, tuples, n, lr, atomic, qoff, flush_at, hot_flush, st);
+    case REC_TRANSREC_L1: return wide_dispatch<REC_TRANSREC_L1>(m, tuples, n, lr, atomic, qoff, flush_at, hot_flush, st);
     default: rec_set_error("the wide update kernel is not available for this model"); return -1;
     }
 }

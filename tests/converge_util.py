@@ -115,11 +115,13 @@ def best_of_trajectory_mid(r, options, precision=F32, seed=0):
         e.set_option(k, v)
     e.init_params(seed)
     best = None
+    traj = []
     for it in range(1, r["epochs"] + 1):
         e.sgd_epoch(0.05, e.steps_per_epoch, seed=seed, epoch=it)
         if it % r["every"] == 0:
             m, _, _ = e.eval(want_counts=False)
+            traj.append([it, m.auc_val, m.auc_test, m.hit_val, m.hit_test])   # the layout of the reference's trajectories
             if best is None or m.auc_val > best[1]:
                 best = (it, m.auc_val, m.auc_test, m.hit_test)
     e.close()
-    return dict(best_iter=best[0], best_auc_val=best[1], auc_test_at_best=best[2], hit50_test_at_best=best[3])
+    return dict(best_iter=best[0], best_auc_val=best[1], auc_test_at_best=best[2], hit50_test_at_best=best[3], trajectory=traj)

@@ -218,3 +218,41 @@ def test_wide_owner_mode_conserves_what_the_step_conserves(model, K):
         touched = np.zeros(I, bool); touched[t[:, 1]] = True; touched[t[:, 2]] = True
         assert np.array_equal(items1[~touched], items0[~touched])
         e.close()
+
+
+@pytest.mark.parametrize("model,K", [("BPRMF", 64), ("MC", 32), ("BPRMF", 16)])
+def test_hot_item_accumulators_conserve_what_the_step_conserves(model, K):
+    """Owner mode of the wide kernel with hot items: the positives are drawn from 30 items only (far above any hot
+    threshold, and all of them get one of the 32 accumulator slots), so every positive's delta goes through a workgroup's hot-item accumulator, is flushed by count
+    and at the end of the launch.  Column sums of the item table must still not move (f32 rounding only), and the items
+    nobody named must be untouched."""
+    rng = np.random.default_rng(17)
+    U, I, n = 100_000, 9_000, 100_000
+    seq_off = np.arange(U + 1, dtype=np.int64) * 3
+    hot_pool = rng.choice(I, 30, replace=False)
+    seq_item = hot_pool[rng.integers(0, 30, 3 * U)].astype(np.int32)        # training occurrences concentrate on the pool
+    test = rng.integers(0, I, U).astype(np.int32); val = rng.integers(0, I, U).astype(np.int32)
+    o = orc.Oracle(model, U, I, K, seq_off, seq_item, test, val, lam=0.0, bias_reg=0.0)
+    W0 = rng.uniform(-0.3, 0.3, o.nw).astype(np.float32).astype(np.float64)
+    first = rng.permutation(U)[:n] if model == "BPRMF" else hot_pool[rng.integers(0, 30, n)]
+    t = np.stack([first, hot_pool[rng.integers(0, 30, n)], rng.integers(0, I, n), np.zeros(n)], 1).astype(np.int32)
+    for hot_flush in (1, 8, 60000):
+        e = ra.Engine(model, I, seq_off, seq_item, test, val, K=K, lam=0.0, bias_reg=0.0, precision=F32)
+        e.set_option("update_policy", 0)      # atomics on every row ...
+        e.set_option("hot_count", 1000)       # ... except the hot items' (each pool item occurs ~10000 times)
+        e.set_option("owner_neg", 1); e.set_option("owner_min", 1); e.set_option("hot_flush", hot_flush)
+        e.upload(W0)
+        e.sgd_replay(0.05, t, HOGWILD)
+        W1 = e.download()
+        off = I + U * K if model == "BPRMF" else I * K
+        items0, items1 = W0[off:].reshape(I, K), W1[off:].reshape(I, K)
+        assert np.abs(items1 - items0).max() > 1e-2
+        drift = np.abs(items1.sum(0) - items0.sum(0)).max()
+        assert drift < 5e-3, (model, K, hot_flush, drift)
+        touched = np.zeros(I, bool); touched[t[:, 1]] = True; touched[t[:, 2]] = True
+        assert np.array_equal(items1[~touched], items0[~touched])
+        if model == "MC":
+            g0, g1 = W0[:I * K].reshape(I, K), W1[:I * K].reshape(I, K)       # the source items' table: only pool rows move
+            src = np.zeros(I, bool); src[t[:, 0]] = True
+            assert np.array_equal(g1[~src], g0[~src]) and np.abs(g1[src] - g0[src]).max() > 1e-3
+        e.close()
