@@ -192,6 +192,7 @@ def main():
     ap.add_argument("--share-negative", type=int, default=0, help="share_negative of the group models (1, 2); 0 = engine default")
     ap.add_argument("--user-batch", type=int, default=0, help="user_batch of the history models (1, 2, 4, 8); 0 = engine default")
     ap.add_argument("--owner", type=int, default=-1, help="owner_neg: negatives' deltas summed in LDS by the workgroup that owns their slice of the catalog (0, 1); -1 = engine default")
+    ap.add_argument("--part-tile", type=int, default=0, help="tuples the owner mode's partition sorts in LDS at a time (0 = engine default)")
     ap.add_argument("--owner-flush", type=int, default=0, help="owner_flush (additions per atomic row); 0 = engine default")
     ap.add_argument("--cpu-ref-eval-users", type=int, default=1000, help="users the reference binary's model::AUC is timed on (0 = skip)")
     ap.add_argument("--wide", type=int, default=-1, help="wide: the four-components-per-lane form of the update kernel (0, 1); -1 = engine default")
@@ -267,7 +268,7 @@ def main():
     HISTORY_MODELS = ("Fossil", "FossilSimple", "REBUS")
     big = eng.steps_per_epoch >= (1 << 22)
     # the engine's defaults (rec_create), overridden by the flags
-    mode = {"policy": 1 if big else 0, "owner": 1 if big and args.model in GROUP_MODELS else 0, "owner_flush": 8,
+    mode = {"policy": 1 if big else 0, "owner": 0, "owner_flush": 8,
             "neg_share": 1, "pos_share": 1, "group": 0}
     if args.policy >= 0:
         eng.set_option("update_policy", args.policy); mode["policy"] = args.policy
@@ -289,12 +290,14 @@ def main():
         eng.set_option("owner_neg", args.owner); mode["owner"] = args.owner
     if args.owner_flush > 0:
         eng.set_option("owner_flush", args.owner_flush); mode["owner_flush"] = args.owner_flush
+    if args.part_tile > 0:
+        eng.set_option("part_tile", args.part_tile)
     if mode["group"] or mode["pos_share"] == 2 or args.overlap:
         mode["owner"] = 0   # the engine falls back to the plain kernel in these modes
     eng.set_option("profile", 1)
     steps_per_epoch = eng.steps_per_epoch
     my_steps = steps_per_epoch // world
-    if my_steps < (1 << 20):
+    if my_steps < (1 << 20) or 8 * I < (1 << 20):
         mode["owner"] = 0   # launches below "owner_min" are not partitioned
 
     def barrier(e=None):
@@ -385,10 +388,14 @@ def main():
             ar = float(atomic_rows)
             if md["owner"]:
                 # negatives whose item has an LDS accumulator cost one atomic row per owner_flush additions
-                slice_rows = (I + 255) // 256
+                slices = e.owner_slices
+                slice_rows = (I + slices - 1) // slices
                 acc_w = K * (2 if args.model in ("FPMC", "PRME") else 1)
-                res = min(slice_rows, (160 * 1024 - 2048) // (acc_w * esz_ + 4))
+                hot_w = K * {"MC": 2, "FPMC": 3, "PRME": 2}.get(args.model, 1)
+                lds = 160 * 1024 - 1280 - 16 * 1024 - 32 * (hot_w * esz_ + 12)   # less the staging areas and the hot items' accumulators
+                res = min(slice_rows, lds // (acc_w * esz_ + 4 + (4 if args.model == "BPRMF" else 0)))
                 frac_res = res / slice_rows
+                roof["owner_slices"] = slices; roof["negatives_resident"] = round(frac_res, 4)
                 ar -= neg_rows * frac_res * (1.0 - 1.0 / md["owner_flush"])
             elif args.model in GROUP_MODELS:
                 if md["neg_share"] > 1 or md["pos_share"] == 2:
@@ -460,11 +467,15 @@ def main():
             r = measure(eng, md, args.precision, vsteps, 1, epoch0=1000 * (len(variants) + 1))
             variants[name] = {"triples_per_sec": r["value"], "ms_per_step": r["ms_per_step"], "update": r["update"], "roofline": r["roofline"]}
 
-        if mode["owner"]:
-            variant("atomics_per_tuple", {"owner_neg": 0}, dict(mode, owner=0))
-            variant("pairs_share_negative", {"owner_neg": 0, "share_negative": 2}, dict(mode, owner=0, neg_share=2))
-            variant("plain_stores", {"share_negative": 1, "update_policy": 2}, dict(mode, owner=0, policy=2))
-            eng.set_option("update_policy", mode["policy"]); eng.set_option("owner_neg", 1)
+        if mode["policy"] == 1 and not mode["owner"]:
+            # options that trade fidelity for fewer float atomics (accuracy of each: DESIGN.md)
+            variant("pairs_share_negative", {"share_negative": 2}, dict(mode, neg_share=2))
+            variant("plain_stores", {"share_negative": 1, "update_policy": 2}, dict(mode, policy=2))
+            eng.set_option("update_policy", 1)
+            if eng.owner_slices > 0 and 8 * I >= (1 << 20):
+                variant("owner_neg_8_per_item", {"owner_neg": 1}, dict(mode, owner=1))
+                variant("owner_neg_one_launch_per_epoch", {"owner_per_item": 1 << 20}, dict(mode, owner=1))
+                eng.set_option("owner_neg", 0); eng.set_option("owner_per_item", 8)
         if args.precision == "f32":
             e64 = ra.Engine(args.model, I, seq_off, seq_item, test_item, val_item, K=K, L=L, lam=0.01, bias_reg=0.01,
                             relation_reg=0.01, alpha=0.5, precision=F64, device=local_rank, user_begin=ub, user_end=ue)

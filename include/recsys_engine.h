@@ -130,9 +130,11 @@ int rec_sample_events(rec_engine* e, int64_t n_expected, uint64_t seed, uint64_t
 int rec_sample_tuples(rec_engine* e, int64_t n, uint64_t seed, uint64_t epoch, int32_t* tuples_out);
 
 /* No counterpart in the reference: the partition step of the update's owner mode ("owner_neg") alone, for inspection.
- * The n tuples ordered by the slice of the catalog their negative item lies in (256 slices of ceil(n_items / 256)
- * consecutive items): out receives the tuples, qoff_out[0..256] where each slice starts in it. */
-int rec_partition_tuples(rec_engine* e, const int32_t* tuples, int64_t n, int32_t* out, int64_t* qoff_out);
+ * The n tuples ordered by the slice of the catalog their negative item lies in (`slices` = 256, 512 or 1024 slices of
+ * ceil(n_items / slices) consecutive items): out receives the tuples, qoff_out[0..slices] where each slice starts in it.
+ * rec_owner_slices: the number of slices this engine's update launches use (0: the model has no owner mode). */
+int rec_partition_tuples(rec_engine* e, const int32_t* tuples, int64_t n, int32_t slices, int32_t* out, int64_t* qoff_out);
+int rec_owner_slices(rec_engine* e);
 
 /* number of updateFactors calls per epoch: num_pos_events (src/model.hpp:47-51), MC: num_pos_trans (MC.cpp:19-22) */
 int64_t rec_steps_per_epoch(const rec_engine* e);

@@ -13,7 +13,7 @@ F32, F64 = 0, 1
 SEQUENTIAL, HOGWILD = 0, 1
 
 EXPORTS = ["rec_last_error", "rec_create", "rec_destroy", "rec_sync", "rec_nw", "rec_params_upload",
-           "rec_params_download", "rec_params_read", "rec_params_init", "rec_snapshot_best", "rec_restore_best", "rec_sgd_replay", "rec_sgd_replay_static", "rec_partition_tuples",
+           "rec_params_download", "rec_params_read", "rec_params_init", "rec_snapshot_best", "rec_restore_best", "rec_sgd_replay", "rec_sgd_replay_static", "rec_partition_tuples", "rec_owner_slices",
            "rec_sgd_epoch", "rec_sample_tuples", "rec_sample_events", "rec_tuples_drawn", "rec_steps_per_epoch", "rec_eval", "rec_eval_sampled", "rec_eval_topk", "rec_eval_sums",
            "rec_rebus_build_paths", "rec_fsub_mine", "rec_num_tables", "rec_table_info", "rec_set_option", "rec_kernel_stats"]
 
@@ -190,12 +190,16 @@ class Engine:
         _check(lib().rec_sample_tuples(self.handle, C.c_int64(n), C.c_uint64(seed), C.c_uint64(epoch), _p(out)))
         return out
 
-    def partition_tuples(self, tuples):
-        """The owner mode's partition alone: (tuples ordered by the negative's slice, slice starts [257])."""
+    @property
+    def owner_slices(self):
+        return int(lib().rec_owner_slices(self.handle))
+
+    def partition_tuples(self, tuples, slices=256):
+        """The owner mode's partition alone: (tuples ordered by the negative's slice, slice starts [slices + 1])."""
         tuples = np.ascontiguousarray(tuples, np.int32)
         out = np.zeros_like(tuples)
-        qoff = np.zeros(257, np.int64)
-        _check(lib().rec_partition_tuples(self.handle, _p(tuples), C.c_int64(len(tuples)), _p(out), _p(qoff)))
+        qoff = np.zeros(slices + 1, np.int64)
+        _check(lib().rec_partition_tuples(self.handle, _p(tuples), C.c_int64(len(tuples)), C.c_int32(slices), _p(out), _p(qoff)))
         return out, qoff
 
     def sample_events(self, n_expected, seed, epoch, cap=None):

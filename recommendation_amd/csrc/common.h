@@ -9,7 +9,6 @@
 #define REC_MAX_EPL 4   // elements per lane: K <= 64 * REC_MAX_EPL
 #define REC_MAX_K (64 * REC_MAX_EPL)
 #define REC_MAX_L 32
-#define REC_HOT_SLOTS 32   // hot items that get an accumulator of their own in every workgroup of the wide owner kernel
 
 // Everything a kernel needs to know about the model and the corpus; passed by value.
 struct DevModel {
@@ -51,12 +50,9 @@ struct DevModel {
     const float* ev_alias_p;            // [n_ev]
     const int32_t* ev_alias_i;          // [n_ev] slot inside the item's range
     const int32_t* train_count;         // [I] occurrences of each item in the training sequences (MostPopular)
-    // [I+1] 0 = ordinary item; otherwise a "hot" item (see rec_set_option "hot_count"): its rows are not scattered with
-    // per-tuple atomics.  1 .. REC_HOT_SLOTS: the item has accumulator slot (value - 1) in the owner mode of the wide
-    // kernel (hot_items[slot] = the item); 255: hot without a slot.
+    // [I+1] 0 = ordinary item, 1 = a "hot" item (see rec_set_option "hot_count"): its rows get plain stores where
+    // the others get float atomics
     const uint8_t* hot;
-    const int32_t* hot_items;           // [REC_HOT_SLOTS] item of each accumulator slot (-1: unused)
-    int n_hot_slots;
 };
 
 // table indices, in the flat order of each model's getParametersFromVector / parametersToFlatVector
@@ -97,12 +93,13 @@ int launch_sgd_owner(const DevModel& m, int precision, const int4* partitioned, 
 // The wide form of the Hogwild kernel (sgd_wide.hip): f32 tables, K and KK multiples of 4; qoff as for launch_sgd_owner
 // (nullptr: plain mode on the tuples as they come)
 bool sgd_wide_supported(const DevModel& m, int precision);
-int launch_sgd_wide(const DevModel& m, const int4* tuples, const int64_t* qoff, int64_t n, double lr, int atomic, int flush_at, int hot_flush, hipStream_t st);
+int sgd_wide_owner_slices(const DevModel& m);
+int launch_sgd_wide(const DevModel& m, const int4* tuples, const int64_t* qoff, int slices, int64_t n, double lr, int atomic, int flush_at, hipStream_t st);
 // Stable-by-block partition of n tuples by (component `field`) / slice_rows into `slices` ranges of dst; qoff[slices+1]
-// (device) receives the range starts.  scratch: partition_scratch_bytes(n, slices).
+// (device) receives the range starts; slices = 256, 512 or 1024.  scratch: partition_scratch_bytes(n, slices).
 size_t partition_scratch_bytes(int64_t n, int slices);
 int launch_partition_by_slice(const int4* src, int4* dst, int64_t n, int field, int slice_rows, int slices, void* scratch,
-                              int64_t* qoff, hipStream_t st);
+                              int64_t* qoff, hipStream_t st, int tile = 0);
 int launch_apply_global(const DevModel& m, int precision, double lr, int64_t n_tuples, double cap, hipStream_t st);
 // max_in_flight: upper bound on the tuples being worked on at the same time (0 = as many as the chip holds).
 // batch (1, 2, 4, 8): the tuples come in aligned groups of `batch` consecutive tuples of one user; one wavefront

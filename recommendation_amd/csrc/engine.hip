@@ -58,8 +58,10 @@ struct rec_engine {
     int wide = 1;        // 1: the wide form of the Hogwild kernel (sgd_wide.hip) where it applies
     int owner = 0;       // 1: launches of >= owner_min tuples are partitioned by the negative's slice of the catalog and applied in owner mode
     int owner_flush = 8; // additions after which an LDS accumulator row is moved to memory
-    int hot_flush = 64;  // the same for the accumulators of the hot items (per workgroup and table)
+    int64_t owner_per_item = 8;   // owner mode: a launch holds at most this many tuples per item of the catalog
     int64_t owner_min = 1 << 20;
+    int part_tile = 0;   // tuples the partition sorts in LDS at a time (0: its default)
+    int owner_slices = 0;   // slices of the catalog in owner mode (0: as few as keep every accumulator in LDS)
     void* part_scratch = nullptr; size_t part_scratch_bytes = 0;
     int64_t* qoff_dev = nullptr;
     int group = 0;       // 1: run-combining update kernel on the tuples as they come; 2: also sample by event, which yields chunks grouped by positive item
@@ -341,10 +343,6 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     if (hipMalloc(&hot, I + 64) != hipSuccess) { rec_set_error("hipMalloc failed"); return fail(-2); }
     e->owned.push_back(hot); (void)hipMemset(hot, 0, I + 64);
     m.hot = (const uint8_t*)hot;
-    void* hot_items = nullptr;
-    if (hipMalloc(&hot_items, sizeof(int32_t) * REC_HOT_SLOTS) != hipSuccess) { rec_set_error("hipMalloc failed"); return fail(-2); }
-    e->owned.push_back(hot_items); (void)hipMemset(hot_items, 0xff, sizeof(int32_t) * REC_HOT_SLOTS);
-    m.hot_items = (const int32_t*)hot_items; m.n_hot_slots = 0;
     // All tuples of one launch may be computed from the same parameter values.  With a small catalog a launch is
     // therefore kept short enough that an item row receives about two updates per launch on average; with a
     // large catalog the number of tuples the chip has in flight (tens of thousands) is below that bound anyway.
@@ -384,15 +382,14 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     // pairs are only the default where histories are long; "user_batch" sets it either way.
     const double mean_history = U > 0 ? (double)E / (double)U : 0.0;
     e->user_batch = (history_model(d->model) && e->steps_per_epoch >= (1 << 22) && mean_history >= 16.0) ? 2 : 1;
-    // The other models: launches of a large epoch run in owner mode (sgd_hogwild.hip) - partitioned by the negative's
-    // slice of the catalog, the negatives' deltas summed in LDS - which removes most of the float atomics the
-    // negatives cost while every step keeps the reference's independent negative.  Not TransRec, whose step is bound
-    // by the arithmetic of its projections.  ("share_negative" 2, pairs of steps drawing one negative, is the older
-    // way to the same saving; it changes the joint distribution of consecutive steps and stays an option.)
-    const bool transrec = d->model == REC_TRANSREC || d->model == REC_TRANSREC_L1;
-    // (where the wide kernel applies - f32 tables, K a multiple of 4: only that kernel also keeps the hot items' sums in
-    // LDS; the one-dword-per-lane form is issue-bound and gains little)
-    e->owner = (!history_model(d->model) && !transrec && sgd_wide_supported(e->dm, d->precision) && e->steps_per_epoch >= (1 << 22)) ? 1 : 0;
+    // Owner mode ("owner_neg": launches partitioned by the negative's slice of the catalog, the negatives' deltas summed in
+    // LDS by the workgroup that owns the slice) removes half of the float atomics, which bound the update kernel, but it
+    // is off by default: within a launch an item's steps in the negative's role come when its workgroup gets to them,
+    // not when they were drawn, and reach memory a few steps late.  BPRMF K = 64 on the 1M x 200k x 100M corpus, test AUC
+    // after 3 epochs against 0.7313 with atomics per tuple: 0.7307 / 0.7298 / 0.7285 / 0.7278 / 0.7188 for launches of
+    // 1 / 2 / 4 / 8 / 16 tuples per item, 0.658 (HIT@50 0.02 against 0.10) for one launch per epoch; the launches short
+    // enough to follow are too short to be faster (46 ms per epoch at 8 per item against 47).
+    e->owner = 0;
     e->neg_share = 1;
     *out = e;
     return 0;
@@ -635,9 +632,8 @@ static int ensure_events(rec_engine* e)
     return 0;
 }
 
-static int ensure_partition_scratch(rec_engine* e, int64_t n)
+static int ensure_partition_scratch(rec_engine* e, int64_t n, int slices)
 {
-    const int slices = sgd_owner_slices();
     const size_t need = partition_scratch_bytes(n, slices);
     if (e->part_scratch_bytes < need) {
         ENG_HIP(hipStreamSynchronize(e->st));
@@ -646,7 +642,7 @@ static int ensure_partition_scratch(rec_engine* e, int64_t n)
         ENG_HIP(hipMalloc(&e->part_scratch, need));
         e->part_scratch_bytes = need;
     }
-    if (!e->qoff_dev) { ENG_HIP(hipMalloc((void**)&e->qoff_dev, sizeof(int64_t) * (slices + 8))); }
+    if (!e->qoff_dev) { ENG_HIP(hipMalloc((void**)&e->qoff_dev, sizeof(int64_t) * (1024 + 8))); }
     return 0;
 }
 
@@ -664,23 +660,33 @@ static int launch_update(rec_engine* e, const int4* tuples, int64_t n, double lr
     // Small catalogs: the history kernel bounds the tuples in flight inside one launch (one tuple per wavefront, so
     // fewer wavefronts); the group kernels are launched in windows of that many tuples.
     if (!history && e->stale_window > 0 && e->stale_window < window) window = e->stale_window;
+    // Owner mode: workgroup s applies the launch's tuples whose negative lies in slice s, so within a launch an item's steps
+    // in the negative's role come when its workgroup gets to them, not when they were drawn.  Over a whole epoch (490
+    // such steps per item on the 200k-item corpus, each moving the item's bias by lr / 4 against as many in the positive's
+    // role) a workgroup that runs ahead or has a shorter list leaves its items too high for the rest of the launch, and
+    // the ranking falls apart (test AUC after one epoch 0.65 against 0.727, HIT@50 0.0003 against 0.09).  Launches of at
+    // most owner_per_item tuples per item keep that imbalance to a few steps per item.
+    const bool owner_able = e->owner && !history && !grouped && e->group == 0 && !e->overlap && sgd_owner_supported(model);
+    const int64_t owner_window = std::max<int64_t>(4096, e->owner_per_item * (int64_t)e->dm.I);
+    const bool owner_on = owner_able && owner_window >= e->owner_min && n >= e->owner_min;
+    if (owner_on && owner_window < window) window = owner_window;
     if (window < n && (user_batch > 1 || e->neg_share > 1 || e->pos_share > 1) && window > 8) window &= ~(int64_t)7;   // launches start on a group boundary
     for (int64_t o = 0; o < n; o += window) {
         const int64_t len = std::min(window, n - o);
         // owner mode: needs room for the partitioned copy, which is the second half of the engine's tuple buffer
         const bool use_wide = e->wide && !history && e->neg_share == 1 && e->pos_share == 1 && sgd_wide_supported(e->dm, e->desc.precision);
         const bool in_own_buffer = e->tuples && tuples + o >= e->tuples && tuples + o + len <= e->tuples + e->tuples_cap;
-        if (e->owner && !history && !grouped && e->group == 0 && !e->overlap && in_own_buffer && len >= e->owner_min &&
-            sgd_owner_supported(model)) {
-            const int slices = sgd_owner_slices();
-            if (int rc = ensure_partition_scratch(e, len)) return rc;
+        if (owner_on && in_own_buffer && len >= e->owner_min) {
+            const int slices = !use_wide ? sgd_owner_slices() : e->owner_slices ? e->owner_slices : sgd_wide_owner_slices(e->dm);
+            const int slice_rows = (e->dm.I + slices - 1) / slices;
+            if (int rc = ensure_partition_scratch(e, len, slices)) return rc;
             int4* dst = (int4*)(tuples + o) + e->tuples_cap;
             hipEvent_t pa = nullptr, pb = nullptr;
             if (e->profile) { ENG_HIP(hipEventCreate(&pa)); ENG_HIP(hipEventCreate(&pb)); ENG_HIP(hipEventRecord(pa, e->st)); }
-            int rc = launch_partition_by_slice(tuples + o, dst, len, sgd_owner_neg_field(model), sgd_owner_slice_rows(e->dm), slices,
-                                               e->part_scratch, e->qoff_dev, e->st);
+            int rc = launch_partition_by_slice(tuples + o, dst, len, sgd_owner_neg_field(model), slice_rows, slices,
+                                               e->part_scratch, e->qoff_dev, e->st, e->part_tile);
             if (e->profile) { ENG_HIP(hipEventRecord(pb, e->st)); e->pending[3].push_back({pa, pb}); }
-            if (!rc) rc = use_wide ? launch_sgd_wide(e->dm, dst, e->qoff_dev, len, lr, e->atomic, e->owner_flush, e->hot_flush, e->st)
+            if (!rc) rc = use_wide ? launch_sgd_wide(e->dm, dst, e->qoff_dev, slices, len, lr, e->atomic, e->owner_flush, e->st)
                                    : launch_sgd_owner(e->dm, e->desc.precision, dst, e->qoff_dev, len, lr, e->atomic, e->owner_flush, e->st);
             if (rc) return rc;
             if (global_row) {
@@ -690,7 +696,7 @@ static int launch_update(rec_engine* e, const int4* tuples, int64_t n, double lr
         }
         int rc = history ? launch_sgd_history(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic, e->stale_window, user_batch, e->st)
                  : ((grouped || e->group == 1) && sgd_runs_supported(model)) ? launch_sgd_runs(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic, e->run_segment, e->run_policy, e->st)
-                 : use_wide ? launch_sgd_wide(e->dm, tuples + o, nullptr, len, lr, e->atomic, 1, 1, e->st)
+                 : use_wide ? launch_sgd_wide(e->dm, tuples + o, nullptr, 0, len, lr, e->atomic, 1, e->st)
                          : launch_sgd_hogwild(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic | ((e->neg_share >= 4 ? 2 : (e->neg_share == 2 || e->pos_share == 2) ? 1 : 0) << 16), e->st);
         if (rc) return rc;
         if (global_row) {
@@ -875,19 +881,26 @@ extern "C" int rec_sample_events(rec_engine* e, int64_t n_expected, uint64_t see
     return 0;
 }
 
-extern "C" int rec_partition_tuples(rec_engine* e, const int32_t* tuples, int64_t n, int32_t* out, int64_t* qoff_out)
+extern "C" int rec_owner_slices(rec_engine* e)
+{
+    if (!e) { rec_set_error("null argument"); return -1; }
+    if (!sgd_owner_supported(e->desc.model)) return 0;
+    return !(e->wide && sgd_wide_supported(e->dm, e->desc.precision)) ? sgd_owner_slices() : e->owner_slices ? e->owner_slices : sgd_wide_owner_slices(e->dm);
+}
+
+extern "C" int rec_partition_tuples(rec_engine* e, const int32_t* tuples, int64_t n, int32_t slices, int32_t* out, int64_t* qoff_out)
 {
     if (!e || !tuples || !out || !qoff_out) { rec_set_error("null argument"); return -1; }
     if (!sgd_owner_supported(e->desc.model)) { rec_set_error("the owner mode is not available for this model"); return -1; }
+    if (slices != 256 && slices != 512 && slices != 1024) { rec_set_error("slices must be 256, 512 or 1024"); return -1; }
     if (n <= 0) return 0;
     ENG_HIP(hipSetDevice(e->desc.device));
     if (int rc = check_tuples(e, tuples, n)) return rc;
     if (int rc = ensure_tuples(e, n)) return rc;
-    if (int rc = ensure_partition_scratch(e, n)) return rc;
-    const int slices = sgd_owner_slices();
+    if (int rc = ensure_partition_scratch(e, n, slices)) return rc;
     ENG_HIP(hipMemcpyAsync(e->tuples, tuples, sizeof(int4) * n, hipMemcpyHostToDevice, e->st));
-    if (int rc = launch_partition_by_slice(e->tuples, e->tuples + e->tuples_cap, n, sgd_owner_neg_field(e->desc.model), sgd_owner_slice_rows(e->dm),
-                                           slices, e->part_scratch, e->qoff_dev, e->st)) return rc;
+    if (int rc = launch_partition_by_slice(e->tuples, e->tuples + e->tuples_cap, n, sgd_owner_neg_field(e->desc.model), (e->dm.I + slices - 1) / slices,
+                                           slices, e->part_scratch, e->qoff_dev, e->st, e->part_tile)) return rc;
     ENG_HIP(hipMemcpyAsync(out, e->tuples + e->tuples_cap, sizeof(int4) * n, hipMemcpyDeviceToHost, e->st));
     ENG_HIP(hipMemcpyAsync(qoff_out, e->qoff_dev, sizeof(int64_t) * (slices + 1), hipMemcpyDeviceToHost, e->st));
     ENG_HIP(hipStreamSynchronize(e->st));
@@ -1062,31 +1075,21 @@ extern "C" int rec_set_option(rec_engine* e, const char* name, int64_t value)
     else if (s == "wide") { if (value != 0 && value != 1) { rec_set_error("wide must be 0 or 1"); return -1; } e->wide = (int)value; }
     else if (s == "owner_neg") { if (value != 0 && value != 1) { rec_set_error("owner_neg must be 0 or 1"); return -1; } e->owner = (int)value; }
     else if (s == "owner_flush") { if (value < 1 || value > 65536) { rec_set_error("owner_flush must be in 1..65536"); return -1; } e->owner_flush = (int)value; }
-    else if (s == "hot_flush") { if (value < 1 || value > 65536) { rec_set_error("hot_flush must be in 1..65536"); return -1; } e->hot_flush = (int)value; }
+    else if (s == "owner_per_item") { if (value < 1) { rec_set_error("owner_per_item must be positive"); return -1; } e->owner_per_item = value; }
+    else if (s == "owner_slices") { if (value != 0 && value != 256 && value != 512 && value != 1024) { rec_set_error("owner_slices must be 0, 256, 512 or 1024"); return -1; } e->owner_slices = (int)value; }
+    else if (s == "part_tile") { if (value != 0 && value != 4096 && value != 7168) { rec_set_error("part_tile must be 0, 4096 or 7168"); return -1; } e->part_tile = (int)value; }
     else if (s == "owner_min") { if (value < 1) { rec_set_error("owner_min must be positive"); return -1; } e->owner_min = value; }
     else if (s == "run_segment") { if (value < 0) { rec_set_error("run_segment must be >= 0"); return -1; } e->run_segment = value; }
     else if (s == "group_by_item") { if (value < 0 || value > 3) { rec_set_error("group_by_item must be 0..3"); return -1; } e->group = (int)value; }
     else if (s == "hot_count") {
-        // items with at least `value` training occurrences are "hot" (0 = none); the REC_HOT_SLOTS most frequent of them
-        // get an accumulator slot (flag = slot + 1), the others the flag 255
+        // items with at least `value` training occurrences are "hot" (0 = none)
         ENG_HIP(hipSetDevice(e->desc.device));
         ENG_HIP(hipStreamSynchronize(e->st));
         const int I = e->I;
         std::vector<uint8_t> flags((size_t)I + 1, 0);
-        std::vector<int32_t> slots(REC_HOT_SLOTS, -1);
-        int n_slots = 0;
-        if (value > 0) {
-            std::vector<std::pair<int32_t, int32_t>> hot;   // (-count, item): most frequent first, ties by item id
-            for (int i = 0; i < I; i++) if (e->train_count_host[i] >= value) hot.push_back({-e->train_count_host[i], i});
-            std::sort(hot.begin(), hot.end());
-            for (size_t k = 0; k < hot.size(); k++) {
-                if ((int)k < REC_HOT_SLOTS) { flags[hot[k].second] = (uint8_t)(k + 1); slots[k] = hot[k].second; n_slots = (int)k + 1; }
-                else flags[hot[k].second] = 255;
-            }
-        }
+        if (value > 0)
+            for (int i = 0; i < I; i++) if (e->train_count_host[i] >= value) flags[i] = 1;
         ENG_HIP(hipMemcpy((void*)e->dm.hot, flags.data(), flags.size(), hipMemcpyHostToDevice));
-        ENG_HIP(hipMemcpy((void*)e->dm.hot_items, slots.data(), sizeof(int32_t) * REC_HOT_SLOTS, hipMemcpyHostToDevice));
-        e->dm.n_hot_slots = n_slots;
     }
     else { rec_set_error("unknown option " + s); return -1; }
     return 0;

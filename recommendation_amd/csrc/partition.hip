@@ -1,16 +1,18 @@
 // Partition of a launch's tuples by the slice of the catalog one of their items lies in (a counting sort with at most
-// 256 bins): histogram per segment, offsets, scatter.  The owner mode of the Hogwild update kernel (sgd_hogwild.hip)
+// 1024 bins): histogram per segment, offsets, scatter.  The owner mode of the Hogwild update kernel (sgd_hogwild.hip)
 // consumes the result: slice s of the output is applied by workgroup s.
 //
 // A block owns a segment of PART_SEG consecutive tuples in both passes.  The scatter pass sorts a tile of PART_TILE
 // tuples by bin inside LDS first, so that a bin's tuples of a tile leave as one contiguous run (16 tuples = 256 B on
-// average with 256 bins) instead of as single 16-byte stores to 256 different places.
+// average with 512 bins) instead of as single 16-byte stores to 256 different places.
 #include "common.h"
 
-constexpr int PART_BINS = 256;
+constexpr int PART_BINS = 1024;              // at most; the launch says how many are in use
 constexpr int PART_THREADS = 1024;
-constexpr int PART_TILE = 4096;              // tuples sorted in LDS at a time (64 KB)
-constexpr int PART_SEG = 4 * PART_TILE;      // tuples per block
+constexpr int PART_SEG = 28672;              // tuples per block (a multiple of every tile size)
+// tuples sorted in LDS at a time: 4096 (72 KB with the bin numbers, two blocks per CU) or 7168 (126 KB, one block per CU,
+// runs 1.75 times as long)
+static_assert(PART_SEG % 4096 == 0 && PART_SEG % 7168 == 0, "whole tiles per segment");
 
 __device__ __forceinline__ int part_bin(const int4& t, int field, int slice_rows)
 {
@@ -19,16 +21,16 @@ __device__ __forceinline__ int part_bin(const int4& t, int field, int slice_rows
 
 // counts[bin * P + block] = tuples of the block's segment that fall into the bin
 __global__ void __launch_bounds__(PART_THREADS) part_hist_kernel(const int4* __restrict__ src, int64_t n, int field, int slice_rows,
-                                                                 int* __restrict__ counts, int P)
+                                                                 int* __restrict__ counts, int P, int bins)
 {
     __shared__ int hist[PART_BINS];
-    if (threadIdx.x < PART_BINS) hist[threadIdx.x] = 0;
+    if (threadIdx.x < bins) hist[threadIdx.x] = 0;
     __syncthreads();
     const int64_t s0 = (int64_t)blockIdx.x * PART_SEG;
     const int64_t s1 = s0 + PART_SEG < n ? s0 + PART_SEG : n;
     for (int64_t i = s0 + threadIdx.x; i < s1; i += PART_THREADS) atomicAdd(&hist[part_bin(src[i], field, slice_rows)], 1);
     __syncthreads();
-    if (threadIdx.x < PART_BINS) counts[(int64_t)threadIdx.x * P + blockIdx.x] = hist[threadIdx.x];
+    if (threadIdx.x < bins) counts[(int64_t)threadIdx.x * P + blockIdx.x] = hist[threadIdx.x];
 }
 
 // block b: exclusive scan of counts[b * P .. (b + 1) * P) in place; total[b] = their sum
@@ -68,17 +70,19 @@ __global__ void part_scan_total_kernel(const int64_t* __restrict__ total, int bi
     }
 }
 
+template <int BINS, int PART_TILE>
 __global__ void __launch_bounds__(PART_THREADS) part_scatter_kernel(const int4* __restrict__ src, int4* __restrict__ dst, int64_t n, int field,
                                                                     int slice_rows, const int* __restrict__ counts, int P,
                                                                     const int64_t* __restrict__ qoff)
 {
+    constexpr int bins = BINS;
     extern __shared__ __align__(16) unsigned char part_lds[];
     int4* stage = (int4*)part_lds;                                          // [PART_TILE] the tile, ordered by bin
-    uint8_t* sbin = (uint8_t*)(part_lds + sizeof(int4) * PART_TILE);       // [PART_TILE] bin of each staged tuple
-    __shared__ int hist[PART_BINS], loff[PART_BINS];
-    __shared__ int64_t gbase[PART_BINS];                                   // where the block's next tuple of each bin goes
-    __shared__ int wsum[4];
-    if (threadIdx.x < PART_BINS) {
+    uint16_t* sbin = (uint16_t*)(part_lds + sizeof(int4) * PART_TILE);     // [PART_TILE] bin of each staged tuple
+    __shared__ int hist[BINS], loff[BINS];
+    __shared__ int64_t gbase[BINS];                                   // where the block's next tuple of each bin goes
+    __shared__ int wsum[BINS / 64];
+    if (threadIdx.x < bins) {
         gbase[threadIdx.x] = qoff[threadIdx.x] + counts[(int64_t)threadIdx.x * P + blockIdx.x];
         hist[threadIdx.x] = 0;
     }
@@ -97,8 +101,8 @@ __global__ void __launch_bounds__(PART_THREADS) part_scatter_kernel(const int4* 
             if (i < cnt) { t[q] = src[t0 + i]; bin[q] = part_bin(t[q], field, slice_rows); rank[q] = atomicAdd(&hist[bin[q]], 1); }
         }
         __syncthreads();
-        // exclusive scan of the 256 bin counts by the first 256 threads
-        if (threadIdx.x < PART_BINS) {
+        // exclusive scan of the bin counts by the first `bins` threads (a multiple of 64)
+        if (threadIdx.x < bins) {
             const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
             const int x = hist[threadIdx.x];
             int inc = x;
@@ -108,7 +112,7 @@ __global__ void __launch_bounds__(PART_THREADS) part_scatter_kernel(const int4* 
             loff[threadIdx.x] = inc - x;   // within the wavefront so far
         }
         __syncthreads();
-        if (threadIdx.x < PART_BINS) {
+        if (threadIdx.x < bins) {
             const int wv = threadIdx.x >> 6;
             int base = 0;
             for (int q = 0; q < wv; q++) base += wsum[q];
@@ -117,7 +121,7 @@ __global__ void __launch_bounds__(PART_THREADS) part_scatter_kernel(const int4* 
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < PER; q++)
-            if (bin[q] >= 0) { const int at = loff[bin[q]] + rank[q]; stage[at] = t[q]; sbin[at] = (uint8_t)bin[q]; }
+            if (bin[q] >= 0) { const int at = loff[bin[q]] + rank[q]; stage[at] = t[q]; sbin[at] = (uint16_t)bin[q]; }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < PER; q++) {
@@ -125,7 +129,7 @@ __global__ void __launch_bounds__(PART_THREADS) part_scatter_kernel(const int4* 
             if (i < cnt) { const int b = sbin[i]; dst[gbase[b] + (i - loff[b])] = stage[i]; }
         }
         __syncthreads();
-        if (threadIdx.x < PART_BINS) { gbase[threadIdx.x] += hist[threadIdx.x]; hist[threadIdx.x] = 0; }
+        if (threadIdx.x < bins) { gbase[threadIdx.x] += hist[threadIdx.x]; hist[threadIdx.x] = 0; }
         __syncthreads();
     }
 }
@@ -137,21 +141,35 @@ size_t partition_scratch_bytes(int64_t n, int slices)
     return sizeof(int) * (size_t)slices * (size_t)part_blocks(n) + sizeof(int64_t) * (size_t)(slices + 8);
 }
 
+template <int BINS, int TILE>
+static int launch_scatter(const int4* src, int4* dst, int64_t n, int field, int slice_rows, const int* counts, int P, const int64_t* qoff, hipStream_t st)
+{
+    const size_t lds = (sizeof(int4) + sizeof(uint16_t)) * TILE;
+    HIP_TRY(hipFuncSetAttribute((const void*)part_scatter_kernel<BINS, TILE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((part_scatter_kernel<BINS, TILE>), dim3(P), dim3(PART_THREADS), lds, st, src, dst, n, field, slice_rows, counts, P, qoff);
+    return 0;
+}
+
+// slices: 256, 512 or 1024.  tile: 4096 or 7168 tuples sorted in LDS at a time (0: the default for that many slices)
 int launch_partition_by_slice(const int4* src, int4* dst, int64_t n, int field, int slice_rows, int slices, void* scratch,
-                              int64_t* qoff, hipStream_t st)
+                              int64_t* qoff, hipStream_t st, int tile)
 {
     if (n <= 0) return 0;
-    if (slices != PART_BINS || slice_rows < 1 || (field != 2 && field != 3)) { rec_set_error("partition: unsupported geometry"); return -1; }
+    if ((slices != 256 && slices != 512 && slices != 1024) || slice_rows < 1 || (field != 2 && field != 3) || (tile != 0 && tile != 4096 && tile != 7168)) {
+        rec_set_error("partition: unsupported geometry"); return -1;
+    }
+    if (tile == 0) tile = slices == 256 ? 4096 : 7168;
     const int P = part_blocks(n);
     int* counts = (int*)scratch;
     int64_t* total = (int64_t*)((char*)scratch + sizeof(int) * (size_t)slices * (size_t)P);
-    hipLaunchKernelGGL(part_hist_kernel, dim3(P), dim3(PART_THREADS), 0, st, src, n, field, slice_rows, counts, P);
+    hipLaunchKernelGGL(part_hist_kernel, dim3(P), dim3(PART_THREADS), 0, st, src, n, field, slice_rows, counts, P, slices);
     hipLaunchKernelGGL(part_scan_bin_kernel, dim3(slices), dim3(256), 0, st, counts, P, total);
     hipLaunchKernelGGL(part_scan_total_kernel, dim3(1), dim3(64), 0, st, (const int64_t*)total, slices, qoff);
-    const size_t lds = sizeof(int4) * PART_TILE + PART_TILE;
-    HIP_TRY(hipFuncSetAttribute((const void*)part_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(part_scatter_kernel, dim3(P), dim3(PART_THREADS), lds, st, src, dst, n, field, slice_rows, (const int*)counts, P,
-                       (const int64_t*)qoff);
+    int rc;
+    if (slices == 256) rc = tile == 4096 ? launch_scatter<256, 4096>(src, dst, n, field, slice_rows, counts, P, qoff, st) : launch_scatter<256, 7168>(src, dst, n, field, slice_rows, counts, P, qoff, st);
+    else if (slices == 512) rc = tile == 4096 ? launch_scatter<512, 4096>(src, dst, n, field, slice_rows, counts, P, qoff, st) : launch_scatter<512, 7168>(src, dst, n, field, slice_rows, counts, P, qoff, st);
+    else rc = tile == 4096 ? launch_scatter<1024, 4096>(src, dst, n, field, slice_rows, counts, P, qoff, st) : launch_scatter<1024, 7168>(src, dst, n, field, slice_rows, counts, P, qoff, st);
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return 0;
 }

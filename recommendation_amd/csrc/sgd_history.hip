@@ -141,6 +141,7 @@ __global__ void __launch_bounds__(256) sgd_history_batch_kernel(DevModel m, cons
             int pos[G], neg[G], np[G], prevl[G];   // prevl: lane ind holds the ind-th previous item of tuple g
             int hp[G], hn[G];                      // hot flags of pos / neg, fetched with their rows
             T vp[G][EPL], vn[G][EPL], sp[G][EPL], sn[G][EPL];
+            double spd[G][EPL], snd[G][EPL];   // the sums over the history in fp64 whatever the tables' type (see REBUS below)
 #pragma unroll
             for (int g = 0; g < G; g++) {
                 const bool valid = g < ng;
@@ -152,7 +153,7 @@ __global__ void __launch_bounds__(256) sgd_history_batch_kernel(DevModel m, cons
                 hp[g] = (valid && (at_item || at_bias)) ? m.hot[pos[g]] : 0; hn[g] = (valid && (at_item || at_bias)) ? m.hot[neg[g]] : 0;
 #pragma unroll
                 for (int j = 0; j < EPL; j++) {
-                    const int k = lane + 64 * j; sp[g][j] = sn[g][j] = 0;
+                    const int k = lane + 64 * j; sp[g][j] = sn[g][j] = 0; spd[g][j] = snd[g][j] = 0;
                     vp[g][j] = (valid && k < K) ? V[(int64_t)pos[g] * K + k] : (T)0;
                     vn[g][j] = (valid && k < K) ? V[(int64_t)neg[g] * K + k] : (T)0;
                 }
@@ -167,7 +168,7 @@ __global__ void __launch_bounds__(256) sgd_history_batch_kernel(DevModel m, cons
                     const bool a = c != pos[g], b = c != neg[g];
                     cp[g] += a; cn[g] += b;
 #pragma unroll
-                    for (int j = 0; j < EPL; j++) { sp[g][j] += a ? x[j] : (T)0; sn[g][j] += b ? x[j] : (T)0; }
+                    for (int j = 0; j < EPL; j++) { spd[g][j] += a ? (double)x[j] : 0.0; snd[g][j] += b ? (double)x[j] : 0.0; }
                 }
                 return false;
             });
@@ -188,7 +189,7 @@ __global__ void __launch_bounds__(256) sgd_history_batch_kernel(DevModel m, cons
                 wp[g] = cp[g] > 0 ? rpow((T)cp[g], (T)-0.2) : (T)0; wn[g] = cn[g] > 0 ? rpow((T)cn[g], (T)-0.2) : (T)0;
                 if (g >= ng) { wp[g] = wn[g] = 0; deri[g] = 0; continue; }
 #pragma unroll
-                for (int j = 0; j < EPL; j++) { sp[g][j] *= wp[g]; sn[g][j] *= wn[g]; }
+                for (int j = 0; j < EPL; j++) { sp[g][j] = (T)((double)wp[g] * spd[g][j]); sn[g][j] = (T)((double)wn[g] * snd[g][j]); }
                 T grad_mine = 0;
                 for (int ind = 0; ind < np[g]; ind++) {
                     const int c = uni(__shfl(prevl[g], ind, 64));
@@ -274,6 +275,9 @@ __global__ void __launch_bounds__(256) sgd_history_batch_kernel(DevModel m, cons
             int tpos[G], pos[G], neg[G], np[G], pathl[G];   // pathl / etal: lane r holds the r-th item of tuple g's matched path and its weight
             T etal[G];
             T pp[G][EPL], pn[G][EPL], sp[G][EPL], sn[G][EPL];
+            // the sums over the history are kept in fp64 whatever the tables' type: a history of thousands of items summed
+            // in f32 is off by ~1e-4 of the sum, which the two squared distances then turn into an error of that size in x_uij
+            double spd[G][EPL], snd[G][EPL];
             int tmax = 0;
 #pragma unroll
             for (int g = 0; g < G; g++) {
@@ -292,7 +296,7 @@ __global__ void __launch_bounds__(256) sgd_history_batch_kernel(DevModel m, cons
                 tmax = tpos[g] > tmax ? tpos[g] : tmax;
 #pragma unroll
                 for (int j = 0; j < EPL; j++) {
-                    const int k = lane + 64 * j; sp[g][j] = sn[g][j] = 0;
+                    const int k = lane + 64 * j; spd[g][j] = snd[g][j] = 0;
                     pp[g][j] = (valid && k < K) ? P[(int64_t)pos[g] * K + k] : (T)0;
                     pn[g][j] = (valid && k < K) ? P[(int64_t)neg[g] * K + k] : (T)0;
                 }
@@ -309,7 +313,7 @@ __global__ void __launch_bounds__(256) sgd_history_batch_kernel(DevModel m, cons
                     if (in && !a) pos_in |= 1u << g;
                     if (in && !b) neg_in |= 1u << g;
 #pragma unroll
-                    for (int j = 0; j < EPL; j++) { sp[g][j] += a ? x[j] : (T)0; sn[g][j] += b ? x[j] : (T)0; }
+                    for (int j = 0; j < EPL; j++) { spd[g][j] += a ? (double)x[j] : 0.0; snd[g][j] += b ? (double)x[j] : 0.0; }
                 }
                 return false;
             });
@@ -333,7 +337,7 @@ __global__ void __launch_bounds__(256) sgd_history_batch_kernel(DevModel m, cons
                 T qp = 0, qn = 0;
 #pragma unroll
                 for (int j = 0; j < EPL; j++) {
-                    sp[g][j] = wp[g] * sp[g][j] + sl[j] - pp[g][j]; sn[g][j] = wn[g] * sn[g][j] + sl[j] - pn[g][j];
+                    sp[g][j] = (T)((double)wp[g] * spd[g][j]) + sl[j] - pp[g][j]; sn[g][j] = (T)((double)wn[g] * snd[g][j]) + sl[j] - pn[g][j];
                     qp += sp[g][j] * sp[g][j]; qn += sn[g][j] * sn[g][j];
                 }
                 const T bpos = bp[g], bneg = bn[g];

@@ -190,10 +190,8 @@ __global__ void __launch_bounds__(OWNER ? OWNER_THREADS : 256) sgd_hogwild_kerne
             const T b0 = NB == 2 ? __shfl(bs, 2 * b, LPT) : (T)0, b1 = NB == 2 ? __shfl(bs, 2 * b + 1, LPT) : (T)0;
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                // rows of hot items fall back to plain stores: their atomics would serialize on one address (not the negative's
-                // rows in owner mode: one workgroup sums them in LDS, and plain stores of the tuples it applies at the same
-                // moment would overwrite each other)
-                at[b][r] = ((atomic >> r) & 1) && ((OWNER && owned_row<MODEL>(r)) || !__shfl(hf, b * R + r, LPT));
+                // rows of hot items fall back to plain stores in either mode: their atomics would serialize on one address
+                at[b][r] = ((atomic >> r) & 1) && !__shfl(hf, b * R + r, LPT);
             }
             const T deri = step<MODEL, T, LPT, EPL>(m, lr, g, v[b], b0, b1, rg, racc, at[b]);
             if ((g >> 1) == b) mine = deri;
@@ -400,7 +398,7 @@ template <int MODEL, class T>
 static int dispatch_shape(const DevModel& m, const int4* tuples, int64_t n, double lr, int atomic, const int64_t* qoff, int flush_at, hipStream_t st)
 {
     const int Kmax = m.K > m.KK ? m.K : m.KK;
-    OwnerArgs ow = {nullptr, 0, 0, 0, 1, 0, 0, 1};
+    OwnerArgs ow = {nullptr, 0, 0, 0, 1};
     size_t lds = 0;
     if (qoff) {
         ow.qoff = qoff; ow.slice_rows = sgd_owner_slice_rows(m); ow.flush_at = flush_at < 1 ? 1 : flush_at;

@@ -241,8 +241,9 @@ struct Seq {
         T* Vp = V + (int64_t)pos * K; T* Vn = V + (int64_t)neg * K; T* Up = Ui + (int64_t)prev * K;
         const int32_t* h = m.seq_item + m.seq_off[u]; const int n = (int)(m.seq_off[u + 1] - m.seq_off[u]);
         T sp[E], sn[E];
+        double spd[E], snd[E];   // sums over a whole history: fp64 whatever the tables' type (thousands of f32 additions lose ~1e-4 of the sum)
 #pragma unroll
-        for (int j = 0; j < E; j++) sp[j] = sn[j] = 0;
+        for (int j = 0; j < E; j++) { sp[j] = sn[j] = 0; spd[j] = snd[j] = 0; }
         int cp = 0, cn = 0;
         for (int t = 0; t < n; t++) {
             const int it = h[t]; const T* Uh = Ui + (int64_t)it * K;
@@ -251,7 +252,7 @@ struct Seq {
 #pragma unroll
             for (int j = 0; j < E; j++) {
                 int k = lane + 64 * j;
-                if (k < K) { T x = Uh[k]; if (it != pos) sp[j] += x; if (it != neg) sn[j] += x; }
+                if (k < K) { const double x = (double)Uh[k]; if (it != pos) spd[j] += x; if (it != neg) snd[j] += x; }
             }
         }
         T wp = cp > 0 ? rpow((T)cp, (T)-0.2) : 0, wn = cn > 0 ? rpow((T)cn, (T)-0.2) : 0;
@@ -261,8 +262,8 @@ struct Seq {
         for (int j = 0; j < E; j++) {
             int k = lane + 64 * j;
             if (k < K) {
-                sp[j] = wp * sp[j] + a0 * Up[k];
-                sn[j] = wn * sn[j] + a0 * Up[k];
+                sp[j] = (T)((double)wp * spd[j]) + a0 * Up[k];
+                sn[j] = (T)((double)wn * snd[j]) + a0 * Up[k];
                 d1 += sp[j] * Vp[k]; d2 += sn[j] * Vn[k];
             }
         }
@@ -307,8 +308,9 @@ struct Seq {
         const int pos = h[tpos]; const int np = tpos < L ? tpos : L;
         T* Vp = V + (int64_t)pos * K; T* Vn = V + (int64_t)neg * K;
         T sp[E], sn[E];
+        double spd[E], snd[E];   // sums over a whole history: fp64 whatever the tables' type (thousands of f32 additions lose ~1e-4 of the sum)
 #pragma unroll
-        for (int j = 0; j < E; j++) sp[j] = sn[j] = 0;
+        for (int j = 0; j < E; j++) { sp[j] = sn[j] = 0; spd[j] = snd[j] = 0; }
         int cp = 0, cn = 0;
         for (int t = 0; t < n; t++) {
             const int it = h[t]; const T* Uh = Ui + (int64_t)it * K;
@@ -317,12 +319,12 @@ struct Seq {
 #pragma unroll
             for (int j = 0; j < E; j++) {
                 int k = lane + 64 * j;
-                if (k < K) { T x = Uh[k]; if (it != pos) sp[j] += x; if (it != neg) sn[j] += x; }
+                if (k < K) { const double x = (double)Uh[k]; if (it != pos) spd[j] += x; if (it != neg) snd[j] += x; }
             }
         }
         T wp = cp > 0 ? rpow((T)cp, (T)-0.2) : 0, wn = cn > 0 ? rpow((T)cn, (T)-0.2) : 0;
 #pragma unroll
-        for (int j = 0; j < E; j++) { sp[j] *= wp; sn[j] *= wn; }
+        for (int j = 0; j < E; j++) { sp[j] = (T)((double)wp * spd[j]); sn[j] = (T)((double)wn * snd[j]); }
         for (int ind = 0; ind < np; ind++) {
             const int c = h[tpos - 1 - ind]; const T* Uc = Ui + (int64_t)c * K;
             const T w = scalar(WT + ind) + scalar(WTu + ind);
@@ -405,9 +407,10 @@ struct Seq {
         const int32_t* path = m.path_item + m.path_off[ctx]; const int np = (int)(m.path_off[ctx + 1] - m.path_off[ctx]);
         const double* etas = m.eta + (int64_t)np * m.L;
         T p_pos[E], p_neg[E], sp[E], sn[E], sl[E], dp[E], dn[E];
+        double spd[E], snd[E];   // sums over the whole prefix: fp64 whatever the tables' type
 #pragma unroll
         for (int j = 0; j < E; j++) {
-            int k = lane + 64 * j; sp[j] = sn[j] = sl[j] = p_pos[j] = p_neg[j] = 0;
+            int k = lane + 64 * j; sp[j] = sn[j] = sl[j] = p_pos[j] = p_neg[j] = 0; spd[j] = snd[j] = 0;
             if (k < K) { p_pos[j] = P[(int64_t)pos * K + k]; p_neg[j] = P[(int64_t)neg * K + k]; }
         }
         int cp = 0, cn = 0;
@@ -419,7 +422,7 @@ struct Seq {
 #pragma unroll
             for (int j = 0; j < E; j++) {
                 int k = lane + 64 * j;
-                if (k < K) { T x = Ph[k]; if (it != pos) sp[j] += x; if (it != neg) sn[j] += x; }
+                if (k < K) { const double x = (double)Ph[k]; if (it != pos) spd[j] += x; if (it != neg) snd[j] += x; }
             }
         }
         T wp = cp > 0 ? rpow((T)cp, (T)m.alpha) : 0, wn = cn > 0 ? rpow((T)cn, (T)m.alpha) : 0;
@@ -433,7 +436,7 @@ struct Seq {
         for (int j = 0; j < E; j++) {
             int k = lane + 64 * j; dp[j] = dn[j] = 0;
             if (k < K) {
-                sp[j] *= wp; sn[j] *= wn;
+                sp[j] = (T)((double)wp * spd[j]); sn[j] = (T)((double)wn * snd[j]);
                 dp[j] = sp[j] + sl[j] - p_pos[j];
                 dn[j] = sn[j] + sl[j] - p_neg[j];
                 qp += dp[j] * dp[j]; qn += dn[j] * dn[j];

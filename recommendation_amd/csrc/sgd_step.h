@@ -102,59 +102,12 @@ template <int MODEL> __device__ __forceinline__ int neg_item(const int4& t) { re
 __device__ __forceinline__ float lds_take(float* p) { return __uint_as_float(atomicExch((unsigned*)p, 0u)); }
 __device__ __forceinline__ double lds_take(double* p) { return __longlong_as_double((long long)atomicExch((unsigned long long*)p, 0ull)); }
 
-// Hot items in the wide owner kernel: the rows a tuple names by an item OTHER than its negative (positive, previous
-// item, MC's source item) belong to one of a model's item tables; a hot item has one accumulator per such table in
-// every workgroup.  hot_seg: which of those tables row r is in (-1: not such a row); the tables lie side by side in an
-// accumulator row.
-template <int MODEL> struct HotSegs;
-template <> struct HotSegs<REC_BPRMF> { static constexpr int N = 1; };      // gamma_item
-template <> struct HotSegs<REC_MC> { static constexpr int N = 2; };         // gamma (source item), eta
-template <> struct HotSegs<REC_FPMC> { static constexpr int N = 3; };       // gamma_item, kappa, eta
-template <> struct HotSegs<REC_PRME> { static constexpr int N = 2; };       // gamma_item, eta
-template <> struct HotSegs<REC_HRM_AVG> { static constexpr int N = 1; };    // V
-template <> struct HotSegs<REC_HRM_MAX> { static constexpr int N = 1; };
-template <> struct HotSegs<REC_TRANSREC> { static constexpr int N = 1; };   // H
-template <> struct HotSegs<REC_TRANSREC_L1> { static constexpr int N = 1; };
-template <int MODEL> __device__ __forceinline__ constexpr int hot_seg(int r)
-{
-    if constexpr (MODEL == REC_BPRMF) return r == 1 ? 0 : -1;
-    else if constexpr (MODEL == REC_MC) return r == 0 ? 0 : r == 1 ? 1 : -1;
-    else if constexpr (MODEL == REC_FPMC) return r == 1 ? 0 : r == 3 ? 1 : r == 4 ? 2 : -1;
-    else if constexpr (MODEL == REC_PRME) return r == 1 ? 0 : (r == 3 || r == 4) ? 1 : -1;
-    else return (r == 1 || r == 2) ? 0 : -1;   // HRM, TransRec
-}
-// first row of the tuple layout that lies in segment `seg` (its table and width are the segment's)
-template <int MODEL> __device__ __host__ __forceinline__ constexpr int hot_seg_row(int seg)
-{
-    if constexpr (MODEL == REC_MC) return seg == 0 ? 0 : 1;
-    else if constexpr (MODEL == REC_FPMC) return seg == 0 ? 1 : seg == 1 ? 3 : 4;
-    else if constexpr (MODEL == REC_PRME) return seg == 0 ? 1 : 3;
-    else return 1;
-}
-template <int MODEL> __device__ __host__ __forceinline__ int hot_seg_off(int seg, int K, int KK)
-{
-    if constexpr (MODEL == REC_MC) return seg * K;
-    else if constexpr (MODEL == REC_FPMC) return seg == 0 ? 0 : seg == 1 ? K : K + KK;
-    else if constexpr (MODEL == REC_PRME) return seg == 0 ? 0 : K;
-    else return 0;
-}
-template <int MODEL> __device__ __host__ __forceinline__ int hot_width(int K, int KK)
-{
-    if constexpr (MODEL == REC_MC) return 2 * K;
-    else if constexpr (MODEL == REC_FPMC) return K + 2 * KK;
-    else if constexpr (MODEL == REC_PRME) return K + KK;
-    else return K;
-}
-
 struct OwnerArgs {
     const int64_t* qoff;   // [slices + 1] where each slice's tuples start in the partitioned buffer
     int slice_rows;        // items per slice
     int rows_res;          // items of a slice with an accumulator row in LDS
     int acc_width;         // elements of an accumulator row (K, or K + KK)
     int flush_at;          // additions after which a row's accumulator is moved to memory
-    int hot_slots;         // wide kernel: hot items with accumulators of their own in every workgroup (0: none)
-    int hot_width;         // elements of a hot item's accumulator row (all its item tables side by side)
-    int hot_flush;         // additions of a workgroup to one table of a hot item after which their sum is moved to memory
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -14,6 +14,13 @@
 // of the wavefront in LDS: every lane writes its four deltas with one ds_write_b128 (the image is row after row), and
 // instruction j of the four atomic instructions adds floats 64j .. 64j+63 of that image: whole rows again.
 //
+// Owner mode keeps its LDS accumulators in 32-bit fixed point (quantum 2^-25): ds_add_f32 retires about one lane every
+// three cycles per CU on this chip (3.2 G rows of 64 floats per second chip-wide, measured: scripts/ubench/lds_atomic.hip -
+// 31 ms for the negatives of one epoch of the 100M-interaction corpus, more than the rest of the kernel), ds_add_u32 runs
+// at the LDS rate (76-120 G rows/s).  A delta is rounded to the nearest quantum (at most 1.5e-8 off, below the f32
+// spacing of a weight of magnitude >= 0.25) before it is added; the sums stay exact, so nothing is lost or doubled, and
+// |sum| must stay below 64 between two flushes.
+//
 // Pipeline, batch claiming and owner mode are those of sgd_hogwild.hip (which documents them); steps that share rows
 // by construction ("share_negative", "share_positive") are not folded here and stay with that kernel.
 #include "common.h"
@@ -22,7 +29,22 @@
 
 constexpr int WIDE_EPL = 4;
 constexpr int WIDE_OWNER_THREADS = 1024;   // one workgroup per CU in owner mode
-constexpr int WIDE_SLICES = 256;
+constexpr float FIX_SCALE = 33554432.f, FIX_INV = 1.f / 33554432.f;   // 2^25
+
+__device__ __forceinline__ void fix_add(int* p, float x) { atomicAdd(p, __float2int_rn(x * FIX_SCALE)); }
+__device__ __forceinline__ void fix_add4(int* p, const float (&x)[4])
+{
+#pragma unroll
+    for (int j = 0; j < 4; j++) fix_add(p + j, x[j]);
+}
+__device__ __forceinline__ float4 fix_read4(const int* p)
+{
+    const int4 a = *reinterpret_cast<const int4*>(p);
+    return make_float4((float)a.x * FIX_INV, (float)a.y * FIX_INV, (float)a.z * FIX_INV, (float)a.w * FIX_INV);
+}
+// reads an accumulator element and leaves zero behind, atomically per element
+__device__ __forceinline__ float fix_take(int* p) { return (float)atomicExch(p, 0) * FIX_INV; }
+__device__ __forceinline__ float4 fix_take4(int* p) { return make_float4(fix_take(p), fix_take(p + 1), fix_take(p + 2), fix_take(p + 3)); }
 
 // FULL: K (and KK) == 4 * LPT, every lane of a group holds four live components (no width tests)
 template <int MODEL, int LPT, int B, bool OWNER, bool FULL>
@@ -38,20 +60,15 @@ __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_ker
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
 
-    // dynamic LDS: [staging: 64 x 4 floats per wavefront][owner mode: accumulators [rows_res][acc_width], ...]
+    // dynamic LDS: [staging: 64 x 4 floats per wavefront][owner mode: accumulators [rows_res][acc_width], counters, bias sums]
     extern __shared__ __align__(16) unsigned char wide_lds[];
     T* stage = (T*)wide_lds + (size_t)wave * 256;
-    T* acc = (T*)wide_lds + (size_t)(blockDim.x >> 6) * 256;
-    // owner mode: [hot_slots][hot_width] sums of this workgroup's deltas to the hot items' other rows (behind acc, so that
-    // both stay 16-byte aligned for the four-float accesses); then the counters: pend [rows_res] additions to an
-    // accumulator row since its last flush, hot_pend [hot_slots][tables] the same per hot item and table
-    constexpr int NSEG = HotSegs<MODEL>::N;
-    T* hot_acc = acc + (size_t)ow.rows_res * ow.acc_width;
-    unsigned* pend = (unsigned*)(hot_acc + (size_t)ow.hot_slots * ow.hot_width);
-    unsigned* hot_pend = pend + ow.rows_res;
-    // owner mode, models with item biases: [rows_res] this workgroup's pending additions to the bias of each resident item
-    // in the negative's role (plain stores of the tuples it applies at the same moment would overwrite each other)
-    T* acc_bias = (T*)(hot_pend + ow.hot_slots * NSEG);
+    int* acc = (int*)wide_lds + (size_t)(blockDim.x >> 6) * 256;
+    // owner mode, behind the accumulators: pend [rows_res] additions to an accumulator row since its last flush; models with
+    // item biases: acc_bias [rows_res] this workgroup's pending additions to the bias of each resident item in the
+    // negative's role (plain stores of the tuples it applies at the same moment would overwrite each other)
+    unsigned* pend = (unsigned*)(acc + (size_t)ow.rows_res * ow.acc_width);
+    int* acc_bias = (int*)(pend + ow.rows_res);
     __shared__ int lds_next;
     const int slice_base = OWNER ? (int)blockIdx.x * ow.slice_rows : 0;
     if constexpr (OWNER) {
@@ -59,8 +76,6 @@ __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_ker
         tuples += q0; n = ow.qoff[blockIdx.x + 1] - q0;
         for (int i = threadIdx.x; i < ow.rows_res * ow.acc_width; i += blockDim.x) acc[i] = 0;
         for (int i = threadIdx.x; i < ow.rows_res; i += blockDim.x) pend[i] = 0;
-        for (int i = threadIdx.x; i < ow.hot_slots * ow.hot_width; i += blockDim.x) hot_acc[i] = 0;
-        for (int i = threadIdx.x; i < ow.hot_slots * NSEG; i += blockDim.x) hot_pend[i] = 0;
         if constexpr (NB == 2) for (int i = threadIdx.x; i < ow.rows_res; i += blockDim.x) acc_bias[i] = 0;
         if (threadIdx.x == 0) lds_next = 0;
         __syncthreads();
@@ -127,7 +142,7 @@ __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_ker
             const T* p = my_bias_ptr(tp);
             if (p) {
                 bs = *p;
-                if ((atomic >> 8) & 1) bias_hot = m.hot[p - (const T*)m.tab[MODEL == REC_BPRMF ? BPRMF_BETA : TR_BETA]];
+                if (((atomic >> 8) & 1) || OWNER) bias_hot = m.hot[p - (const T*)m.tab[MODEL == REC_BPRMF ? BPRMF_BETA : TR_BETA]];
             }
         }
     };
@@ -175,7 +190,11 @@ __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_ker
             const bool ok = tp[b].x >= 0;
             const int sl = slot_of(tp[b]);
             if constexpr (OWNER && NB == 2) {
-                if (sl >= 0 && g == 2 * b + 1) { bias_slot = sl; bs += acc_bias[sl]; }
+                // the negative's bias goes the way of its row: summed in LDS unless the row gets plain stores (whatever the
+                // scatter policy says about biases: the tuples a workgroup applies at the same moment share their negatives,
+                // and plain stores of their bias steps would overwrite each other)
+                constexpr int NEG_ROW = MODEL == REC_BPRMF ? 2 : 3;
+                if (sl >= 0 && g == 2 * b + 1 && ((atomic >> NEG_ROW) & 1) && !bias_hot) { bias_slot = sl; bs += (float)acc_bias[sl] * FIX_INV; }
             }
             T w[R][EPL], old[R][EPL];
 #pragma unroll
@@ -188,34 +207,21 @@ __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_ker
                         if (!owned_row<MODEL>(r)) continue;
                         const int width = ((MODEL == REC_FPMC || MODEL == REC_PRME) && r == 5) ? m.KK : m.K;
                         if (FULL || EPL * g < width) {
-                            const float4 a = *reinterpret_cast<const float4*>(acc + (size_t)sl * ow.acc_width + owned_off<MODEL>(r, m.K) + EPL * g);
+                            const float4 a = fix_read4(acc + (size_t)sl * ow.acc_width + owned_off<MODEL>(r, m.K) + EPL * g);
                             w[r][0] += a.x; w[r][1] += a.y; w[r][2] += a.z; w[r][3] += a.w;
                         }
                     }
                 }
             }
-            // Rows of hot items are not scattered with per-tuple atomics: from all over the chip they would serialize on
-            // one address.  Plain mode: plain racy stores instead.  Owner mode: the negative's rows are summed in LDS whether
-            // hot or not (plain stores of the tuples one workgroup applies at the same moment would overwrite each other),
-            // and a hot item's other rows go to the workgroup's accumulator of that item: no update is lost, and memory
-            // sees one atomic row per hot_flush additions of a workgroup.
-            bool at[R]; int hs[R];   // hs: accumulator slot of the row's hot item (-1: none)
+            // Rows of hot items are not scattered with atomics in either mode: from all over the chip they would serialize on
+            // one address, and summing them exactly (here, or in an accumulator that is flushed now and then) applies
+            // hundreds of steps computed from the same stale row at once - with the regularisation term in every one of them
+            // the row overshoots.  They get plain racy stores, which lose most of the concurrent steps instead.
+            bool at[R];
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const int flag = __shfl(hf, b * R + r, LPT);
-                hs[r] = (OWNER && hot_seg<MODEL>(r) >= 0 && flag >= 1 && flag <= ow.hot_slots) ? flag - 1 : -1;
-                // (owner mode: a hot item beyond the accumulator slots takes per-tuple atomics - its negative's sums arrive as
-                // atomics, and a plain store of old + delta would wipe them out)
-                at[r] = ((atomic >> r) & 1) && (OWNER || !flag);
-                if constexpr (OWNER) {
-                    if (hs[r] >= 0) {
-                        const int width = (hot_seg<MODEL>(r) > 0 && (MODEL == REC_FPMC || MODEL == REC_PRME)) ? m.KK : m.K;
-                        if (FULL || EPL * g < width) {
-                            const float4 a = *reinterpret_cast<const float4*>(hot_acc + (size_t)hs[r] * ow.hot_width + hot_seg_off<MODEL>(hot_seg<MODEL>(r), m.K, m.KK) + EPL * g);
-                            w[r][0] += a.x; w[r][1] += a.y; w[r][2] += a.z; w[r][3] += a.w;
-                        }
-                    }
-                }
+                at[r] = ((atomic >> r) & 1) && !flag;
 #pragma unroll
                 for (int j = 0; j < EPL; j++) old[r][j] = w[r][j];
             }
@@ -233,42 +239,16 @@ __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_ker
                 int width; T* row = row_ptr<MODEL, T>(m, tp[b], r, width);
                 const bool act = ok && (FULL || EPL * g < width);
                 const bool to_acc = OWNER && owned_row<MODEL>(r) && sl >= 0 && at[r];
-                const bool to_hot = OWNER && hs[r] >= 0 && at[r] && ok;
                 if (to_acc) {
                     if (act) {
-                        T* a = acc + (size_t)sl * ow.acc_width + owned_off<MODEL>(r, m.K) + EPL * g;
-#pragma unroll
-                        for (int j = 0; j < EPL; j++) unsafeAtomicAdd(a + j, w[r][j]);
+                        fix_add4(acc + (size_t)sl * ow.acc_width + owned_off<MODEL>(r, m.K) + EPL * g, w[r]);
                     }
                     accumulated = true;
-                } else if (to_hot) {
-                    if (act) {
-                        T* a = hot_acc + (size_t)hs[r] * ow.hot_width + hot_seg_off<MODEL>(hot_seg<MODEL>(r), m.K, m.KK) + EPL * g;
-#pragma unroll
-                        for (int j = 0; j < EPL; j++) unsafeAtomicAdd(a + j, w[r][j]);
-                    }
                 } else if (!at[r]) {
                     if (act) *reinterpret_cast<float4*>(row + EPL * g) = make_float4(old[r][0] + w[r][0], old[r][1] + w[r][1], old[r][2] + w[r][2], old[r][3] + w[r][3]);
                 }
-                if constexpr (OWNER) {
-                    if (hot_seg<MODEL>(r) >= 0) {
-                        // every hot_flush-th addition of this workgroup to the hot item's table moves the sum to memory
-                        bool fire0 = false;
-                        if (to_hot && g == 0) fire0 = atomicInc(hot_pend + hs[r] * NSEG + hot_seg<MODEL>(r), (unsigned)(ow.hot_flush - 1)) == (unsigned)(ow.hot_flush - 1);
-                        const unsigned long long fired = __ballot(fire0);
-                        if (fired) {
-                            const bool fire = (fired >> (lane & ~(LPT - 1))) & 1ull;
-                            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (fire && (FULL || EPL * g < width)) {
-                                T* a = hot_acc + (size_t)hs[r] * ow.hot_width + hot_seg_off<MODEL>(hot_seg<MODEL>(r), m.K, m.KK) + EPL * g;
-                                x = make_float4(lds_take(a), lds_take(a + 1), lds_take(a + 2), lds_take(a + 3));
-                            }
-                            stage_and_flush(x, row_table<MODEL, T>(m, r), width, fire ? row_number<MODEL>(tp[b], r) : -1);
-                        }
-                    }
-                }
                 // atomics: through the staging image, if any group of the wavefront needs them for this row
-                const bool wants = ok && at[r] && !to_acc && !to_hot;
+                const bool wants = ok && at[r] && !to_acc;
                 if (__ballot(wants))
                     stage_and_flush(make_float4(w[r][0], w[r][1], w[r][2], w[r][3]), row_table<MODEL, T>(m, r), width, wants ? row_number<MODEL>(tp[b], r) : -1);
             }
@@ -285,13 +265,12 @@ __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_ker
                         const int width = ((MODEL == REC_FPMC || MODEL == REC_PRME) && r == 5) ? m.KK : m.K;
                         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (fire && (FULL || EPL * g < width)) {
-                            T* a = acc + (size_t)sl * ow.acc_width + owned_off<MODEL>(r, m.K) + EPL * g;
-                            x = make_float4(lds_take(a), lds_take(a + 1), lds_take(a + 2), lds_take(a + 3));
+                            x = fix_take4(acc + (size_t)sl * ow.acc_width + owned_off<MODEL>(r, m.K) + EPL * g);
                         }
                         stage_and_flush(x, row_table<MODEL, T>(m, r), width, fire ? row_number<MODEL>(tp[b], r) : -1);
                     }
                     if constexpr (NB == 2) {
-                        if (fire && g == 0) unsafeAtomicAdd(bias_ptr<MODEL, T>(m, tp[b], 1), lds_take(acc_bias + sl));
+                        if (fire && g == 0) unsafeAtomicAdd(bias_ptr<MODEL, T>(m, tp[b], 1), fix_take(acc_bias + sl));
                     }
                 }
             }
@@ -301,8 +280,10 @@ __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_ker
             T* p = my_bias_ptr(tp);
             const T sgn = ((g & 1) == 0) == (MODEL == REC_BPRMF) ? (T)1 : (T)-1;
             const T delta = p ? lr * (sgn * mine - (T)m.bias_reg * bs) : (T)0;
-            if (p && bias_slot >= 0) unsafeAtomicAdd(acc_bias + bias_slot, delta);
-            else if (p) scatter(p, delta, bs, ((atomic >> 8) & 1) && !bias_hot);
+            if (p && bias_slot >= 0) fix_add(acc_bias + bias_slot, delta);
+            // (owner mode: atomics on the positive's bias as well when its item's rows get them - the negative's steps arrive
+            // as atomic sums, and a plain store of "value loaded a batch ago + step" would wipe out those that landed since)
+            else if (p) scatter(p, delta, bs, (((atomic >> 8) & 1) || (OWNER && ((atomic >> 1) & 1))) && !bias_hot);
         }
         bs = bn; bias_hot = bias_hot_n; hf = hfn;
         b_p = b_n; b_n = b_nn;
@@ -320,39 +301,20 @@ __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_ker
         const int groups = blockDim.x / LPT, gid = threadIdx.x / LPT;
         for (int s0 = 0; s0 < ow.rows_res; s0 += groups) {
             const int sl = s0 + gid;
-            const bool dirty = sl < ow.rows_res && pend[sl] != 0;
+            bool dirty = sl < ow.rows_res && pend[sl] != 0;
+            if constexpr (NB == 2) dirty = dirty || (sl < ow.rows_res && acc_bias[sl] != 0);   // a bias delta is added after its tuple's count
             if (!__ballot(dirty)) continue;
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 if (!owned_row<MODEL>(r)) continue;
                 const int width = ((MODEL == REC_FPMC || MODEL == REC_PRME) && r == 5) ? m.KK : m.K;
                 float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (dirty && (FULL || EPL * g < width)) x = *reinterpret_cast<const float4*>(acc + (size_t)sl * ow.acc_width + owned_off<MODEL>(r, m.K) + EPL * g);
+                if (dirty && (FULL || EPL * g < width)) x = fix_read4(acc + (size_t)sl * ow.acc_width + owned_off<MODEL>(r, m.K) + EPL * g);
                 *reinterpret_cast<float4*>(stage + EPL * lane) = x;
                 flush_stage(row_table<MODEL, T>(m, r), width, dirty ? slice_base + sl : -1);
             }
             if constexpr (NB == 2) {
-                if (dirty && g == 0) unsafeAtomicAdd((T*)m.tab[MODEL == REC_BPRMF ? BPRMF_BETA : TR_BETA] + slice_base + sl, acc_bias[sl]);
-            }
-        }
-        // and the hot items' sums, one group per (slot, table)
-        for (int s0 = 0; s0 < ow.hot_slots * NSEG; s0 += groups) {
-            const int idx = s0 + gid;
-            const bool dirty = idx < ow.hot_slots * NSEG && hot_pend[idx] != 0;
-            if (!__ballot(dirty)) continue;
-            const int slot = idx / NSEG, seg = idx % NSEG;
-            const int item = dirty ? m.hot_items[slot] : -1;
-#pragma unroll
-            for (int sg = 0; sg < NSEG; sg++) {
-                // a wave-instruction of the staged scatter serves one table: the groups take turns by table
-                const bool mine_now = dirty && seg == sg;
-                if (!__ballot(mine_now)) continue;
-                const int rr = sg == 0 ? hot_seg_row<MODEL>(0) : sg == 1 ? hot_seg_row<MODEL>(1) : hot_seg_row<MODEL>(2);
-                const int width = (sg > 0 && (MODEL == REC_FPMC || MODEL == REC_PRME)) ? m.KK : m.K;
-                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (mine_now && (FULL || EPL * g < width)) x = *reinterpret_cast<const float4*>(hot_acc + (size_t)slot * ow.hot_width + hot_seg_off<MODEL>(sg, m.K, m.KK) + EPL * g);
-                *reinterpret_cast<float4*>(stage + EPL * lane) = x;
-                flush_stage(row_table<MODEL, T>(m, rr), width, mine_now ? item : -1);
+                if (dirty && g == 0) unsafeAtomicAdd((T*)m.tab[MODEL == REC_BPRMF ? BPRMF_BETA : TR_BETA] + slice_base + sl, (float)acc_bias[sl] * FIX_INV);
             }
         }
     }
@@ -373,23 +335,43 @@ __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_ker
 // ------------------------------------------------------------------------------------------------ launch
 static size_t wide_owner_lds_budget() { return 160 * 1024 - 1024 - 256; }   // less the kernel's static LDS (TransRec's reduction row)
 
+// LDS layout of the owner mode for `slices` slices of the catalog: fills ow (all but qoff and the flush periods) and
+// returns the dynamic LDS bytes.  rows_res < slice_rows when a slice's accumulators do not fit.
+static size_t wide_owner_layout(const DevModel& m, int slices, OwnerArgs& ow)
+{
+    const bool two = m.model == REC_FPMC || m.model == REC_PRME;
+    const bool biased = m.model == REC_BPRMF || m.model == REC_TRANSREC || m.model == REC_TRANSREC_L1;
+    const size_t stage_bytes = (size_t)(WIDE_OWNER_THREADS / 64) * 1024;
+    ow.slice_rows = (m.I + slices - 1) / slices;
+    ow.acc_width = two ? m.K + m.KK : m.K;
+    const size_t per_row = (size_t)ow.acc_width * sizeof(float) + sizeof(unsigned) + (biased ? sizeof(float) : 0);
+    ow.rows_res = (int)std::min<size_t>((size_t)ow.slice_rows, (wide_owner_lds_budget() - stage_bytes) / per_row);
+    return stage_bytes + (size_t)ow.rows_res * per_row;
+}
+
+// Slices the owner mode cuts the catalog into: the fewest of 256 / 512 / 1024 (one, two or four workgroups per CU, one
+// after the other) with which every item of a slice has its accumulator row in LDS; 1024 if none does.
+int sgd_wide_owner_slices(const DevModel& m)
+{
+    for (int slices = 256; slices < 1024; slices *= 2) {
+        OwnerArgs ow = {};
+        wide_owner_layout(m, slices, ow);
+        if (ow.rows_res >= ow.slice_rows) return slices;
+    }
+    return 1024;
+}
+
 template <int MODEL>
-static int wide_dispatch(const DevModel& m, const int4* tuples, int64_t n, double lr, int atomic, const int64_t* qoff, int flush_at, int hot_flush, hipStream_t st)
+static int wide_dispatch(const DevModel& m, const int4* tuples, int64_t n, double lr, int atomic, const int64_t* qoff, int slices, int flush_at, hipStream_t st)
 {
     const int Kmax = m.K > m.KK ? m.K : m.KK;
-    OwnerArgs ow = {nullptr, 0, 0, 0, 1, 0, 0, 1};
+    OwnerArgs ow = {nullptr, 0, 0, 0, 1};
     auto go = [&](auto kern, auto kern_owner, int lpt, int b) -> int {
         if (qoff) {
-            const size_t stage_bytes = (size_t)(WIDE_OWNER_THREADS / 64) * 1024;
-            ow.qoff = qoff; ow.slice_rows = (m.I + WIDE_SLICES - 1) / WIDE_SLICES; ow.flush_at = flush_at < 1 ? 1 : flush_at;
-            ow.acc_width = (MODEL == REC_FPMC || MODEL == REC_PRME) ? m.K + m.KK : m.K;
-            ow.hot_slots = m.n_hot_slots; ow.hot_width = hot_width<MODEL>(m.K, m.KK); ow.hot_flush = hot_flush < 1 ? 1 : hot_flush;
-            const size_t hot_bytes = (size_t)ow.hot_slots * ((size_t)ow.hot_width * sizeof(float) + sizeof(unsigned) * HotSegs<MODEL>::N);
-            const size_t per_row = (size_t)ow.acc_width * sizeof(float) + sizeof(unsigned) + (Spec<MODEL>::NB == 2 ? sizeof(float) : 0);
-            ow.rows_res = (int)std::min<size_t>((size_t)ow.slice_rows, (wide_owner_lds_budget() - stage_bytes - hot_bytes) / per_row);
-            const size_t lds = stage_bytes + (size_t)ow.rows_res * per_row + hot_bytes;
+            const size_t lds = wide_owner_layout(m, slices, ow);
+            ow.qoff = qoff; ow.flush_at = flush_at < 1 ? 1 : flush_at;
             HIP_TRY(hipFuncSetAttribute((const void*)kern_owner, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern_owner, dim3(WIDE_SLICES), dim3(WIDE_OWNER_THREADS), lds, st, m, tuples, n, (float)lr, atomic, ow);
+            hipLaunchKernelGGL(kern_owner, dim3(slices), dim3(WIDE_OWNER_THREADS), lds, st, m, tuples, n, (float)lr, atomic, ow);
             return 0;
         }
         const int64_t groups_per_block = 256 / lpt;
@@ -426,18 +408,19 @@ bool sgd_wide_supported(const DevModel& m, int precision)
 }
 
 // qoff == nullptr: plain mode on the tuples as they come; else owner mode on tuples partitioned by the negative's slice
-int launch_sgd_wide(const DevModel& m, const int4* tuples, const int64_t* qoff, int64_t n, double lr, int atomic, int flush_at, int hot_flush, hipStream_t st)
+// (`slices` of them, qoff[slices + 1])
+int launch_sgd_wide(const DevModel& m, const int4* tuples, const int64_t* qoff, int slices, int64_t n, double lr, int atomic, int flush_at, hipStream_t st)
 {
     if (n <= 0) return 0;
     switch (m.model) {
-    case REC_BPRMF: return wide_dispatch<REC_BPRMF>(m, tuples, n, lr, atomic, qoff, flush_at, hot_flush, st);
-    case REC_MC: return wide_dispatch<REC_MC>(m, tuples, n, lr, atomic, qoff, flush_at, hot_flush, st);
-    case REC_FPMC: return wide_dispatch<REC_FPMC>(m, tuples, n, lr, atomic, qoff, flush_at, hot_flush, st);
-    case REC_PRME: return wide_dispatch<REC_PRME>(m, tuples, n, lr, atomic, qoff, flush_at, hot_flush, st);
-    case REC_HRM_AVG: return wide_dispatch<REC_HRM_AVG>(m, tuples, n, lr, atomic, qoff, flush_at, hot_flush, st);
-    case REC_HRM_MAX: return wide_dispatch<REC_HRM_MAX>(m, tuples, n, lr, atomic, qoff, flush_at, hot_flush, st);
-    case REC_TRANSREC: return wide_dispatch<REC_TRANSREC>(m, tuples, n, lr, atomic, qoff, flush_at, hot_flush, st);
-    case REC_TRANSREC_L1: return wide_dispatch<REC_TRANSREC_L1>(m, tuples, n, lr, atomic, qoff, flush_at, hot_flush, st);
+    case REC_BPRMF: return wide_dispatch<REC_BPRMF>(m, tuples, n, lr, atomic, qoff, slices, flush_at, st);
+    case REC_MC: return wide_dispatch<REC_MC>(m, tuples, n, lr, atomic, qoff, slices, flush_at, st);
+    case REC_FPMC: return wide_dispatch<REC_FPMC>(m, tuples, n, lr, atomic, qoff, slices, flush_at, st);
+    case REC_PRME: return wide_dispatch<REC_PRME>(m, tuples, n, lr, atomic, qoff, slices, flush_at, st);
+    case REC_HRM_AVG: return wide_dispatch<REC_HRM_AVG>(m, tuples, n, lr, atomic, qoff, slices, flush_at, st);
+    case REC_HRM_MAX: return wide_dispatch<REC_HRM_MAX>(m, tuples, n, lr, atomic, qoff, slices, flush_at, st);
+    case REC_TRANSREC: return wide_dispatch<REC_TRANSREC>(m, tuples, n, lr, atomic, qoff, slices, flush_at, st);
+    case REC_TRANSREC_L1: return wide_dispatch<REC_TRANSREC_L1>(m, tuples, n, lr, atomic, qoff, slices, flush_at, st);
     default: rec_set_error("the wide update kernel is not available for this model"); return -1;
     }
 }
