@@ -455,6 +455,35 @@ def main():
                           f", item tables all-reduced (sum of deltas) {trainer.rounds} times per epoch, {sum(t.numel() * t.element_size() for t in trainer.tabs)} bytes each" if trainer else "")},
            "roofline": roofline}
 
+    # ---------------- evaluation: users/s over the full catalog
+    if not args.no_eval:
+        barrier()
+        eng.kernel_stats(1)
+        t0 = time.perf_counter()
+        sums = eng.eval_sums(50)
+        torch.cuda.synchronize()
+        if world > 1:
+            ts = torch.tensor(sums, dtype=torch.float64, device=dev)
+            all_reduce(ts, dist.ReduceOp.SUM)
+            sums = ts.cpu().numpy()
+            dist.barrier()
+        et = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([et], dtype=torch.float64, device=dev)
+            all_reduce(tt, dist.ReduceOp.MAX)
+            et = float(tt.item())
+        sc_ms, sc_n = eng.kernel_stats(1)
+        n_eval = float(sums[7])
+        nctx = 1 if args.model in ("BPRMF", "MP") else 2
+        kq = K * (2 if args.model in ("FPMC", "PRME") else 1)
+        flops = 2.0 * nctx * kq * I * (n_eval / world)   # per rank
+        tf = flops / (sc_ms * 1e-3) / 1e12 if sc_ms > 0 else 0.0
+        out["eval"] = {"users_per_sec": round(n_eval / et, 1), "seconds": round(et, 4), "users": int(n_eval),
+                       "auc_test": round(float(sums[1] / n_eval), 6), "hit50_test": round(float(sums[3] / n_eval), 6),
+                       "roofline": {"bound": "mfma", "kernel": "score_count_kernel", "achieved": round(tf, 2),
+                                    "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4),
+                                    "dtype": "f64", "launch_ms": round(sc_ms, 3)}}
+
     # ---------------- the other scatter modes and f64 storage, same corpus, same measurement (N=1 only)
     if world == 1 and not args.no_variants and args.model in GROUP_MODELS and args.policy < 0 and args.owner < 0 and \
             args.share_negative == 0 and args.share_positive == 0 and args.group < 0:
@@ -485,35 +514,6 @@ def main():
             variants["f64_storage"] = {"triples_per_sec": r["value"], "ms_per_step": r["ms_per_step"], "update": r["update"], "roofline": r["roofline"]}
             e64.close()
         out["variants"] = variants
-
-    # ---------------- evaluation: users/s over the full catalog
-    if not args.no_eval:
-        barrier()
-        eng.kernel_stats(1)
-        t0 = time.perf_counter()
-        sums = eng.eval_sums(50)
-        torch.cuda.synchronize()
-        if world > 1:
-            ts = torch.tensor(sums, dtype=torch.float64, device=dev)
-            all_reduce(ts, dist.ReduceOp.SUM)
-            sums = ts.cpu().numpy()
-            dist.barrier()
-        et = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([et], dtype=torch.float64, device=dev)
-            all_reduce(tt, dist.ReduceOp.MAX)
-            et = float(tt.item())
-        sc_ms, sc_n = eng.kernel_stats(1)
-        n_eval = float(sums[7])
-        nctx = 1 if args.model in ("BPRMF", "MP") else 2
-        kq = K * (2 if args.model in ("FPMC", "PRME") else 1)
-        flops = 2.0 * nctx * kq * I * (n_eval / world)   # per rank
-        tf = flops / (sc_ms * 1e-3) / 1e12 if sc_ms > 0 else 0.0
-        out["eval"] = {"users_per_sec": round(n_eval / et, 1), "seconds": round(et, 4), "users": int(n_eval),
-                       "auc_test": round(float(sums[1] / n_eval), 6), "hit50_test": round(float(sums[3] / n_eval), 6),
-                       "roofline": {"bound": "mfma", "kernel": "score_count_kernel", "achieved": round(tf, 2),
-                                    "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4),
-                                    "dtype": "f64", "launch_ms": round(sc_ms, 3)}}
 
     # ---------------- CPU baseline: the single-thread restatement of BPRMF::oneiteration, rank 0, N=1 only
     if rank == 0 and world == 1 and args.cpu_steps > 0 and args.model == "BPRMF":

@@ -228,11 +228,18 @@ int rec_table_info(const rec_engine* e, int t, void** dev_ptr, int64_t* rows, in
  *   "stale_window"  tuples per update launch for small catalogs (0 = no limit)
  *   "global_window" tuples per update launch for models with a row every tuple touches
  *   "global_cap"    such a row moves by at most this many steps' worth of learning rate per launch
+ *   "eval_screen"   1 (default): with f32 tables the full-catalog sweep of rec_eval runs on the FP32 matrix pipe and decides
+ *                   every comparison it can prove from a rounding bound; the columns within the bound of a threshold are
+ *                   decided in fp64, so the counts are those of the fp64 sweep.  0: fp64 sweep.  (process-wide)
+ *   "eval_screen_cap"  columns per query the screen may leave to fp64 (default 96); a query that needs more makes the
+ *                   whole sweep run again in fp64
  *   "profile"       time every update / scoring / sampler launch with HIP events */
 int rec_set_option(rec_engine* e, const char* name, int64_t value);
 
 /* HIP-event statistics gathered while "profile" = 1: which = 0 SGD update (in owner mode: the partition and the update
- * kernel together), 1 eval scoring kernel, 2 sampler, 3 the owner mode's partition alone.  Resets the counters. */
+ * kernel together), 1 eval scoring kernel, 2 sampler, 3 the owner mode's partition alone.  Resets the counters.
+ * which = 4 (not reset): how the last full-catalog sweep ran - *launches = 0 fp64, 1 f32 screen, 2 screen overflowed and
+ * fp64 took over; *total_ms = the number of columns the screen left to fp64, over all queries. */
 int rec_kernel_stats(rec_engine* e, int which, double* total_ms, int64_t* launches);
 
 #ifdef __cplusplus

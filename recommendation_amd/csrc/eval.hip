@@ -36,6 +36,13 @@ struct EvalDev {
     const double* col_b;       // [columns] b of every scored column (bconst gathered; = bconst when all items are scored)
     const int32_t* item_mult;  // [I] how often an item occurs among the columns (null: once)
     int n_cols;                // number of scored columns
+    // f32 screen (score_screen_kernel): per-query margin, and per query the columns it could not decide
+    float* qmar;               // [nq_pad] |f32 score - exact score| is below this for every column of the query
+    int32_t* amb;              // [nq_pad][amb_cap] undecided columns: item | which thresholds (bits 28, 29)
+    int32_t* amb_cnt;          // [nq_pad] how many (may exceed amb_cap: then *amb_overflow is set and the lists are not used)
+    int amb_cap;
+    int32_t* amb_overflow;
+    const float* tb_max;       // [2] max_j ||T_j||_2 and max_j |b_j|, rounded up
 };
 
 #define E REC_MAX_EPL
@@ -440,6 +447,211 @@ __global__ void __launch_bounds__(256, 2) score_count_kernel(EvalDev ev, const T
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// f32 screen.  When the tables are f32, the sweep above spends its time in FP64 MFMAs on numbers that were f32 to begin
+// with.  This kernel runs the same sweep on the FP32 matrix pipe (twice the rate, half the LDS bytes) and decides every
+// comparison it can PROVE: with u = 2^-24, q32 = fl(q'), and any order of accumulation,
+//     |fl32(b_j + <q32, T_j>) - (b_j + <q', T_j>)|  <=  (KQ + 2) u ||q'|| ||T_j||  +  u (|b_j| + |score|)
+// so a column whose f32 score differs from the f32 threshold by more than the query's margin
+//     M_q = 2 (KQ + 2) u ||q'|| Tmax + 4 u (Bmax + |thr| + ||q'|| Tmax)          (Tmax = max ||T_j||, Bmax = max |b_j|;
+// twice the bound, for an accumulator that truncates instead of rounding) is counted, or not, for certain.  The others -
+// a few dozen of 200k per query - go to the query's list and are decided in fp64 by correct_clicked_kernel with the very
+// summation it uses for the clicked items, so the counts are those of the fp64 sweep.
+// v_mfma_f32_16x16x4_f32 operand maps: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
+// D[i = 4 (lane >> 4) + r][j = lane & 15] for result register r.  The contraction index is permuted so that quad
+// (lane >> 4) owns k = quad * KC .. quad * KC + KC - 1: its B values of an item are contiguous and come as ds_read_b128.
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+template <int KQ> struct ScreenShape {
+    static constexpr int NI = KQ <= 64 ? 64 : KQ <= 128 ? 32 : 16;    // items per tile
+    static constexpr int MT = KQ <= 16 ? 4 : KQ <= 128 ? 2 : 1;       // 16-query tiles per wavefront
+};
+
+template <int KQ, bool TWO>
+__global__ void __launch_bounds__(256, 2) score_screen_kernel(EvalDev ev, const float* __restrict__ seg0, const float* __restrict__ seg1,
+                                                              const int32_t* __restrict__ qtest, const int32_t* __restrict__ qval, int I)
+{
+    constexpr int KC = KQ / 4, NI = ScreenShape<KQ>::NI, MT = ScreenShape<KQ>::MT, STR = KQ + 4;
+    constexpr int PER4 = NI * KQ / 4 / 256;   // float4 tile elements per thread
+    constexpr int QB = 4 * MT * 16;           // queries per block
+    static_assert(PER4 >= 1 && KC % 4 == 0, "tile shape");
+    __shared__ __align__(16) float tile[NI * STR];
+    __shared__ float tile_b[NI];
+    __shared__ float4 q_thr[QB];              // (threshold, second threshold, margin, -)
+    __shared__ int2 q_ex[QB];                 // (test item, validation item): never counted
+    __shared__ int q_amb[QB];                 // undecided columns of the query so far
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, quad = lane >> 4;
+    const int64_t qblock = (int64_t)blockIdx.x * QB;
+    const int qw = wave * (MT * 16);
+    const int K1 = ev.K1, K2 = ev.K2;
+
+    for (int i = tid; i < QB; i += 256) {
+        q_thr[i] = make_float4((float)ev.thr[qblock + i], TWO ? (float)ev.thr2[qblock + i] : 0.f, ev.qmar[qblock + i], 0.f);
+        q_ex[i] = make_int2(qtest[qblock + i], qval[qblock + i]);
+        q_amb[i] = 0;
+    }
+
+    float a[MT][KC];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++) a[mt][kc] = (float)ev.Q[(qblock + qw + mt * 16 + col) * KQ + quad * KC + kc];
+
+    int cnt[MT][4], cnt2[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) { cnt[mt][r] = 0; cnt2[mt][r] = 0; }
+
+    const bool dense = K1 == KQ;
+    auto fetch = [&](int item0, float4 (&pre)[PER4], float& preb) {
+        if (dense && item0 + NI <= I) {
+            const float4* src = reinterpret_cast<const float4*>(seg0 + (int64_t)item0 * KQ) + tid;
+#pragma unroll
+            for (int p = 0; p < PER4; p++) pre[p] = src[256 * p];
+            preb = tid < NI ? (float)ev.col_b[item0 + tid] : 0.f;
+            return;
+        }
+        preb = (tid < NI && item0 + tid < I) ? (float)ev.col_b[item0 + tid] : 0.f;
+#pragma unroll
+        for (int p = 0; p < PER4; p++) {
+            float v[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int idx = 4 * (tid + 256 * p) + c, it = idx / KQ, k = idx % KQ;
+                const int64_t j = (int64_t)item0 + it;
+                const bool ok = j < I && k < K1 + K2;
+                const int64_t jc = j < I ? j : (int64_t)I - 1;
+                const int kk = k < K1 + K2 ? k : 0;
+                float x = 0.f;
+                if (K1 + K2 > 0) x = kk < K1 ? seg0[jc * K1 + kk] : seg1[jc * K2 + (kk - K1)];
+                v[c] = ok ? x : 0.f;
+            }
+            pre[p] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    };
+
+    float4 pre[PER4]; float preb;
+    fetch(0, pre, preb);
+    for (int item0 = 0; item0 < I; item0 += NI) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < PER4; p++) {
+            const int idx = 4 * (tid + 256 * p), it = idx / KQ, k = idx % KQ;
+            *reinterpret_cast<float4*>(&tile[it * STR + k]) = pre[p];
+        }
+        if (tid < NI) tile_b[tid] = preb;
+        __syncthreads();
+        if (item0 + NI < I) fetch(item0 + NI, pre, preb);
+#pragma unroll 1
+        for (int sub = 0; sub < NI / 16; sub++) {
+            const int jj = sub * 16 + col;
+            const int j = item0 + jj;
+            const bool live = j < I;
+            float4_t acc[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) acc[mt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c4 = 0; c4 < KC / 4; c4++) {
+                const float4 b4 = *reinterpret_cast<const float4*>(&tile[jj * STR + quad * KC + 4 * c4]);
+                const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][4 * c4 + c], bv[c], acc[mt], 0, 0, 0);
+            }
+            const float bj = tile_b[jj];
+            unsigned open1 = 0, open2 = 0;   // bit (4 mt + r): that query's (second) threshold is within the margin of this column's score
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int qi = qw + mt * 16 + 4 * quad + r;
+                    const float4 th = q_thr[qi]; const int2 ex = q_ex[qi];
+                    const float sc = acc[mt][r] + bj;
+                    const int ok = (int)live & (int)(j != ex.x) & (int)(j != ex.y);
+                    const float d1 = th.x - sc;
+                    cnt[mt][r] += ok & (int)(d1 > th.z);
+                    open1 |= (unsigned)(ok & (int)(fabsf(d1) <= th.z)) << (4 * mt + r);
+                    if (TWO) {
+                        const float d2 = th.y - sc;
+                        cnt2[mt][r] += ok & (int)(d2 > th.z);
+                        open2 |= (unsigned)(ok & (int)(fabsf(d2) <= th.z)) << (4 * mt + r);
+                    }
+                }
+            // the rare ones: a compact loop, not unrolled
+            unsigned open = open1 | open2;
+            while (open) {
+                const int e = __ffs(open) - 1;
+                open &= open - 1;
+                const int qi = qw + (e >> 2) * 16 + 4 * quad + (e & 3);
+                const int which = (int)((open1 >> e) & 1u) | ((int)((open2 >> e) & 1u) << 1);
+                const int at = atomicAdd(&q_amb[qi], 1);
+                if (at < ev.amb_cap) ev.amb[(qblock + qi) * (int64_t)ev.amb_cap + at] = j | (which << 28);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < QB; i += 256) {
+        ev.amb_cnt[qblock + i] = q_amb[i];
+        if (q_amb[i] > ev.amb_cap) *ev.amb_overflow = 1;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int c = cnt[mt][r], c2 = cnt2[mt][r];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) { c += __shfl_xor(c, o, 64); if (TWO) c2 += __shfl_xor(c2, o, 64); }
+            if (col == 0) {
+                const int64_t qi = qblock + qw + mt * 16 + 4 * quad + r;
+                ev.cnt[qi] = c;
+                if (TWO) ev.cnt2[qi] = c2;
+            }
+        }
+}
+
+// max_j ||T_j||_2 and max_j |b_j| (as the bit patterns of non-negative floats, which order like unsigned integers); one
+// wavefront per item
+__global__ void __launch_bounds__(256) screen_item_bounds_kernel(EvalDev ev, const float* __restrict__ seg0, const float* __restrict__ seg1, int I,
+                                                                 unsigned* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int j = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (j >= I) return;
+    double s = 0;
+    for (int k = lane; k < ev.K1; k += 64) { const double t = (double)seg0[(int64_t)j * ev.K1 + k]; s += t * t; }
+    for (int k = lane; k < ev.K2; k += 64) { const double t = (double)seg1[(int64_t)j * ev.K2 + k]; s += t * t; }
+    s = group_sum<64>(s);
+    if (lane == 0) {
+        const float n = __double2float_ru(sqrt(s) * 1.000001), b = __double2float_ru(fabs(ev.bconst[j]) * 1.000001);
+        // NaN / infinity in the tables: the margins become NaN / infinite and every column goes to the fp64 path or is dropped as there
+        atomicMax(out, __float_as_uint(n == n ? n : INFINITY));
+        atomicMax(out + 1, __float_as_uint(b == b ? b : INFINITY));
+    }
+}
+
+// the margin of every query; one wavefront per query
+__global__ void __launch_bounds__(256) screen_margins_kernel(EvalDev ev, const unsigned* __restrict__ bounds)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w >= ev.nq_pad) return;
+    double s = 0;
+    for (int k = lane; k < ev.KQ; k += 64) { const double q = ev.Q[w * ev.KQ + k]; s += q * q; }
+    s = sqrt(group_sum<64>(s));
+    if (lane == 0) {
+        const double tmax = (double)__uint_as_float(bounds[0]), bmax = (double)__uint_as_float(bounds[1]);
+        const double u = 5.9604644775390625e-08;
+        const double t1 = ev.thr[w], t2 = ev.nctx == 1 ? ev.thr2[w] : 0.0;
+        const double ta = (isfinite(t1) ? fabs(t1) : 0.0) + (isfinite(t2) ? fabs(t2) : 0.0);
+        const double mq = 2.0 * (ev.KQ + 2) * u * s * tmax + 4.0 * u * (bmax + ta + s * tmax) + 1e-30;
+        // a padding row (no query) decides nothing and lists nothing
+        ev.qmar[w] = w < ev.nq ? __double2float_ru(mq * 1.000001) : 0.f;
+    }
+}
+
 // |.|_1 scoring (TransRec_L1): not a contraction, so it runs on the vector ALU.  A block owns QT
 // queries for the whole item sweep; items are staged through LDS in tiles of 64 (odd row stride:
 // conflict-free when the 64 lanes of a wavefront read 64 different items), thread (item jj, query
@@ -556,6 +768,21 @@ __global__ void __launch_bounds__(256) correct_clicked_kernel(DevModel m, EvalDe
     }
     if (!test_clicked) excluded += ev.item_mult ? ev.item_mult[test] : 1;
     if (!val_clicked && val != test) excluded += ev.item_mult ? ev.item_mult[val] : 1;
+    if (ev.amb) {
+        // the columns the f32 screen left open, decided with the summation used for the clicked items above (a clicked
+        // item among them is added here and taken out there by the same comparison)
+        const int na = ev.amb_cnt[w] < ev.amb_cap ? ev.amb_cnt[w] : ev.amb_cap;
+        const int32_t* list = ev.amb + (int64_t)w * ev.amb_cap;
+        for (int i = 0; i < na; i++) {
+            const int ent = list[i], e = ent & 0x0fffffff, which = ent >> 28;
+            double s = 0;
+            for (int k = lane; k < K1; k += 64) s += q[k] * (double)seg0[(int64_t)e * K1 + k];
+            for (int k = lane; k < K2; k += 64) s += q[K1 + k] * (double)seg1[(int64_t)e * K2 + k];
+            s = group_sum<64>(s) + ev.bconst[e];
+            c += ((which & 1) && thr > s) ? 1 : 0;
+            c2 += ((which & 2) && thr2 > s) ? 1 : 0;
+        }
+    }
     if (lane == 0) {
         if (ev.nctx == 1) {
             ev.counts[3 * (int64_t)u] = c; ev.counts[3 * (int64_t)u + 1] = c2;
@@ -611,6 +838,32 @@ static int launch_score(const EvalDev& ev, const T* s0, const T* s1, int n_cols,
 
 static unsigned blocks_for_waves(int64_t waves) { return (unsigned)((waves * 64 + 255) / 256); }
 
+static int g_screen_on = 1, g_screen_cap = 96;
+static int g_screen_mode = 0;           // how the last full-catalog sweep ran: 0 fp64, 1 f32 screen, 2 screen overflowed and fp64 took over
+static int64_t g_screen_open = 0;       // columns the last screen left to fp64, over all queries
+void eval_configure_screen(int on, int cap) { if (on >= 0) g_screen_on = on; if (cap > 0) g_screen_cap = cap; }
+void eval_screen_stats(int* mode, int64_t* open) { *mode = g_screen_mode; *open = g_screen_open; }
+
+static int screen_qblock(int KQ) { return KQ <= 16 ? 256 : KQ <= 128 ? 128 : 64; }
+
+template <bool TWO>
+static int launch_screen(const EvalDev& ev, const float* s0, const float* s1, int n_cols, const int32_t* qtest, const int32_t* qval, hipStream_t st)
+{
+#define SCREEN_CASE(KQv)                                                                                        \
+    case KQv: {                                                                                                 \
+        const unsigned blocks = (unsigned)(ev.nq_pad / (4 * ScreenShape<KQv>::MT * 16));                        \
+        hipLaunchKernelGGL((score_screen_kernel<KQv, TWO>), dim3(blocks), dim3(256), 0, st, ev, s0, s1, qtest, qval, n_cols); \
+        break;                                                                                                  \
+    }
+    switch (ev.KQ) {
+        SCREEN_CASE(16) SCREEN_CASE(32) SCREEN_CASE(64) SCREEN_CASE(128) SCREEN_CASE(256)
+    default: rec_set_error("unsupported query width"); return -1;
+    }
+#undef SCREEN_CASE
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <class T>
 static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host, hipStream_t st, double* score_ms,
                      int64_t* score_launches, bool profile, const int32_t* subset_host, int n_subset)
@@ -640,7 +893,9 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
     const int mt = ev.KQ <= 32 ? 4 : ev.KQ <= 64 ? 2 : 1;
     const bool l1 = m.model == REC_TRANSREC_L1;
     constexpr int L1_QT = 32;
-    const int qblock = l1 ? L1_QT : 4 * mt * 16;
+    // f32 tables, the whole catalog, a contraction: the f32 screen decides what it can prove, fp64 the rest
+    const bool screen = g_screen_on && sizeof(T) == 4 && !l1 && n_subset <= 0 && kw > 0 && I < (1 << 28);
+    const int qblock = l1 ? L1_QT : screen ? std::max(4 * mt * 16, screen_qblock(ev.KQ)) : 4 * mt * 16;
     ev.nq = m.n_eval * ev.nctx;
     ev.nq_pad = ((ev.nq + qblock - 1) / qblock) * qblock;
 
@@ -705,16 +960,53 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
         ev.col_item = d_ids; ev.item_mult = d_mult; ev.col_b = d_b;
     }
 
+    unsigned* bounds = nullptr;
+    if (!l1 && n_subset <= 0) { g_screen_mode = 0; g_screen_open = 0; }
+    if (screen) {
+        ev.amb_cap = g_screen_cap;
+        EV_TRY(alloc((void**)&ev.qmar, sizeof(float) * ev.nq_pad));
+        EV_TRY(alloc((void**)&ev.amb, sizeof(int32_t) * (size_t)ev.nq_pad * ev.amb_cap));
+        EV_TRY(alloc((void**)&ev.amb_cnt, sizeof(int32_t) * ev.nq_pad));
+        EV_TRY(alloc((void**)&ev.amb_overflow, sizeof(int32_t)));
+        EV_TRY(alloc((void**)&bounds, sizeof(unsigned) * 2));
+        EV_TRY(hipMemsetAsync(ev.amb_overflow, 0, sizeof(int32_t), st));
+        EV_TRY(hipMemsetAsync(bounds, 0, sizeof(unsigned) * 2, st));
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (profile) { EV_TRY(hipEventCreate(&e0)); EV_TRY(hipEventCreate(&e1)); EV_TRY(hipEventRecord(e0, st)); }
     int rc = 0;
     if (l1) {
         rc = launch_score_l1<T, false>(ev, seg0_cols, qtest, qval, NC, m.K, st);
+    } else if (screen) {
+        hipLaunchKernelGGL(screen_item_bounds_kernel, dim3(blocks_for_waves(I)), dim3(256), 0, st, ev, (const float*)seg0_cols, (const float*)seg1_cols, I, bounds);
+        ev.tb_max = (const float*)bounds;
+        hipLaunchKernelGGL(screen_margins_kernel, dim3(blocks_for_waves(ev.nq_pad)), dim3(256), 0, st, ev, (const unsigned*)bounds);
+        rc = ev.nctx == 1 ? launch_screen<true>(ev, (const float*)seg0_cols, (const float*)seg1_cols, NC, qtest, qval, st)
+                          : launch_screen<false>(ev, (const float*)seg0_cols, (const float*)seg1_cols, NC, qtest, qval, st);
     } else {
         rc = ev.nctx == 1 ? launch_score<T, true, false>(ev, seg0_cols, seg1_cols, NC, qtest, qval, st)
                           : launch_score<T, false, false>(ev, seg0_cols, seg1_cols, NC, qtest, qval, st);
     }
     if (rc) { release(); return rc; }
+    if (screen) {
+        // a query with more undecided columns than its list holds (tables with huge norms, a model that has diverged):
+        // the whole sweep is done again in fp64
+        int32_t over = 0;
+        EV_TRY(hipMemcpyAsync(&over, ev.amb_overflow, sizeof over, hipMemcpyDeviceToHost, st));
+        EV_TRY(hipStreamSynchronize(st));
+        g_screen_mode = over ? 2 : 1; g_screen_open = 0;
+        if (profile) {
+            std::vector<int32_t> open(ev.nq);
+            EV_TRY(hipMemcpy(open.data(), ev.amb_cnt, sizeof(int32_t) * ev.nq, hipMemcpyDeviceToHost));
+            for (int32_t x : open) g_screen_open += x;
+        }
+        if (over) {
+            ev.amb = nullptr;
+            rc = ev.nctx == 1 ? launch_score<T, true, false>(ev, seg0_cols, seg1_cols, NC, qtest, qval, st)
+                              : launch_score<T, false, false>(ev, seg0_cols, seg1_cols, NC, qtest, qval, st);
+            if (rc) { release(); return rc; }
+        }
+    }
     if (profile) EV_TRY(hipEventRecord(e1, st));
     hipLaunchKernelGGL(correct_clicked_kernel<T>, dim3(blocks_for_waves(ev.nq)), dim3(256), 0, st, m, ev);
     EV_TRY(hipGetLastError());

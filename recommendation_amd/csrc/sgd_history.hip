@@ -333,15 +333,19 @@ __global__ void __launch_bounds__(256) sgd_history_batch_kernel(DevModel m, cons
 #pragma unroll
                     for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; sl[j] += e * (k < K ? P[(int64_t)c * K + k] : (T)0); }
                 }
-                // sp / sn become the two distance vectors from here on
-                T qp = 0, qn = 0;
+                // sp / sn become the two distance vectors from here on.  Their squared lengths grow with the history (|S|^0.8
+                // at alpha = -0.6) and x_uij is their difference: formed and subtracted in fp64, or a history of thousands of
+                // items costs f32 tables 1e-4 in x_uij
+                const double wpd = cp[g] > 0 ? pow((double)cp[g], (double)m.alpha) : 0.0, wnd = cn[g] > 0 ? pow((double)cn[g], (double)m.alpha) : 0.0;
+                double qd = 0;
 #pragma unroll
                 for (int j = 0; j < EPL; j++) {
-                    sp[g][j] = (T)((double)wp[g] * spd[g][j]) + sl[j] - pp[g][j]; sn[g][j] = (T)((double)wn[g] * snd[g][j]) + sl[j] - pn[g][j];
-                    qp += sp[g][j] * sp[g][j]; qn += sn[g][j] * sn[g][j];
+                    const double dp = wpd * spd[g][j] + (double)sl[j] - (double)pp[g][j], dn = wnd * snd[g][j] + (double)sl[j] - (double)pn[g][j];
+                    sp[g][j] = (T)dp; sn[g][j] = (T)dn;
+                    qd += dn * dn - dp * dp;
                 }
                 const T bpos = bp[g], bneg = bn[g];
-                const T x_uij = __shfl(-bpos + bneg, 0, 64) - wsum(qp) + wsum(qn);
+                const T x_uij = __shfl(-bpos + bneg, 0, 64) + (T)group_sum<64>(qd);
                 deri[g] = sigm(x_uij);
                 if (lane == 0) {
                     scat(beta + pos[g], lr * (-deri[g] - breg * bpos), bpos, at_bias && !hp[g]);   // [9]

@@ -431,18 +431,19 @@ struct Seq {
 #pragma unroll
             for (int j = 0; j < E; j++) { int k = lane + 64 * j; if (k < K) sl[j] += e * Pr[k]; }
         }
-        T qp = 0, qn = 0;
+        // the squared lengths of the two distance vectors grow with the history and x is their difference: fp64 throughout
+        const double wpd = cp > 0 ? pow((double)cp, (double)m.alpha) : 0.0, wnd = cn > 0 ? pow((double)cn, (double)m.alpha) : 0.0;
+        double qd = 0;
 #pragma unroll
         for (int j = 0; j < E; j++) {
             int k = lane + 64 * j; dp[j] = dn[j] = 0;
             if (k < K) {
-                sp[j] = (T)((double)wp * spd[j]); sn[j] = (T)((double)wn * snd[j]);
-                dp[j] = sp[j] + sl[j] - p_pos[j];
-                dn[j] = sn[j] + sl[j] - p_neg[j];
-                qp += dp[j] * dp[j]; qn += dn[j] * dn[j];
+                const double a = wpd * spd[j] + (double)sl[j] - (double)p_pos[j], b = wnd * snd[j] + (double)sl[j] - (double)p_neg[j];
+                dp[j] = (T)a; dn[j] = (T)b;
+                qd += b * b - a * a;
             }
         }
-        T x = -(scalar(beta + pos) + wsum(qp)) + (scalar(beta + neg) + wsum(qn));
+        T x = (-scalar(beta + pos) + scalar(beta + neg)) + (T)group_sum<64>(qd);
         T deri = 1 / (1 + rexp(x));
         if (lane == 0) {
             beta[pos] += lr * (-deri - breg * beta[pos]);   // [9]
