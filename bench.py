@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, spec
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix, spec (v_mfma_f64_16x16x4_f64)
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X FP32 matrix, spec (v_mfma_f32_16x16x4_f32)
 
 
 def make_synthetic(n_users, n_items, n_clicks, seed, device):
@@ -478,11 +479,17 @@ def main():
         kq = K * (2 if args.model in ("FPMC", "PRME") else 1)
         flops = 2.0 * nctx * kq * I * (n_eval / world)   # per rank
         tf = flops / (sc_ms * 1e-3) / 1e12 if sc_ms > 0 else 0.0
+        open_cols, sweep_mode = eng.kernel_stats(4)
+        screened = sweep_mode == 1
+        peak = FP32_MFMA_PEAK_TFLOPS if screened else FP64_MFMA_PEAK_TFLOPS
         out["eval"] = {"users_per_sec": round(n_eval / et, 1), "seconds": round(et, 4), "users": int(n_eval),
                        "auc_test": round(float(sums[1] / n_eval), 6), "hit50_test": round(float(sums[3] / n_eval), 6),
-                       "roofline": {"bound": "mfma", "kernel": "score_count_kernel", "achieved": round(tf, 2),
-                                    "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4),
-                                    "dtype": "f64", "launch_ms": round(sc_ms, 3)}}
+                       "roofline": {"bound": "mfma", "kernel": "score_screen_kernel" if screened else "score_count_kernel",
+                                    "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                                    "dtype": "f32 sweep with a proven rounding margin, undecided columns in f64" if screened else "f64",
+                                    "launch_ms": round(sc_ms, 3)}}
+        if screened:
+            out["eval"]["roofline"]["undecided_columns_per_query"] = round(open_cols / max(1.0, n_eval * nctx), 2)
 
     # ---------------- the other scatter modes and f64 storage, same corpus, same measurement (N=1 only)
     if world == 1 and not args.no_variants and args.model in GROUP_MODELS and args.policy < 0 and args.owner < 0 and \

@@ -43,6 +43,7 @@ struct EvalDev {
     int amb_cap;
     int32_t* amb_overflow;
     const float* tb_max;       // [2] max_j ||T_j||_2 and max_j |b_j|, rounded up
+    int heldout_counted;       // 1: the sweep counted the test / validation items like any column (the screen does): taken out afterwards
 };
 
 #define E REC_MAX_EPL
@@ -462,23 +463,23 @@ __global__ void __launch_bounds__(256, 2) score_count_kernel(EvalDev ev, const T
 // (lane >> 4) owns k = quad * KC .. quad * KC + KC - 1: its B values of an item are contiguous and come as ds_read_b128.
 typedef float float4_t __attribute__((ext_vector_type(4)));
 
-template <int KQ> struct ScreenShape {
-    static constexpr int NI = KQ <= 64 ? 64 : KQ <= 128 ? 32 : 16;    // items per tile
+template <int KQ, bool DENSE = false> struct ScreenShape {
+    // items per tile; twice as many when the table fills the query width (a tile is one contiguous run, fetched without
+    // the address arithmetic of the general case, whose registers the larger tile needs)
+    static constexpr int NI = (KQ <= 64 ? 64 : KQ <= 128 ? 32 : 16) * (DENSE ? 2 : 1);
     static constexpr int MT = KQ <= 16 ? 4 : KQ <= 128 ? 2 : 1;       // 16-query tiles per wavefront
 };
 
-template <int KQ, bool TWO>
-__global__ void __launch_bounds__(256, 2) score_screen_kernel(EvalDev ev, const float* __restrict__ seg0, const float* __restrict__ seg1,
+template <int KQ, bool TWO, bool DENSE>
+__global__ void __launch_bounds__(256, DENSE && KQ <= 64 ? 3 : 2) score_screen_kernel(EvalDev ev, const float* __restrict__ seg0, const float* __restrict__ seg1,
                                                               const int32_t* __restrict__ qtest, const int32_t* __restrict__ qval, int I)
 {
-    constexpr int KC = KQ / 4, NI = ScreenShape<KQ>::NI, MT = ScreenShape<KQ>::MT, STR = KQ + 4;
+    constexpr int KC = KQ / 4, NI = ScreenShape<KQ, DENSE>::NI, MT = ScreenShape<KQ, DENSE>::MT, STR = KQ + 4;
     constexpr int PER4 = NI * KQ / 4 / 256;   // float4 tile elements per thread
     constexpr int QB = 4 * MT * 16;           // queries per block
     static_assert(PER4 >= 1 && KC % 4 == 0, "tile shape");
     __shared__ __align__(16) float tile[NI * STR];
     __shared__ float tile_b[NI];
-    __shared__ float4 q_thr[QB];              // (threshold, second threshold, margin, -)
-    __shared__ int2 q_ex[QB];                 // (test item, validation item): never counted
     __shared__ int q_amb[QB];                 // undecided columns of the query so far
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, quad = lane >> 4;
@@ -486,11 +487,17 @@ __global__ void __launch_bounds__(256, 2) score_screen_kernel(EvalDev ev, const 
     const int qw = wave * (MT * 16);
     const int K1 = ev.K1, K2 = ev.K2;
 
-    for (int i = tid; i < QB; i += 256) {
-        q_thr[i] = make_float4((float)ev.thr[qblock + i], TWO ? (float)ev.thr2[qblock + i] : 0.f, ev.qmar[qblock + i], 0.f);
-        q_ex[i] = make_int2(qtest[qblock + i], qval[qblock + i]);
-        q_amb[i] = 0;
-    }
+    for (int i = tid; i < QB; i += 256) q_amb[i] = 0;
+    // thresholds and margin of this lane's 4 MT result rows (held-out items are counted like any column here and taken
+    // out by correct_clicked_kernel: no per-element exclusion test)
+    float th1[MT][4], th2[MT][4], mar[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int64_t qi = qblock + qw + mt * 16 + 4 * quad + r;
+            th1[mt][r] = (float)ev.thr[qi]; th2[mt][r] = TWO ? (float)ev.thr2[qi] : 0.f; mar[mt][r] = ev.qmar[qi];
+        }
 
     float a[MT][KC];
 #pragma unroll
@@ -504,13 +511,16 @@ __global__ void __launch_bounds__(256, 2) score_screen_kernel(EvalDev ev, const 
 #pragma unroll
         for (int r = 0; r < 4; r++) { cnt[mt][r] = 0; cnt2[mt][r] = 0; }
 
-    const bool dense = K1 == KQ;
-    auto fetch = [&](int item0, float4 (&pre)[PER4], float& preb) {
-        if (dense && item0 + NI <= I) {
-            const float4* src = reinterpret_cast<const float4*>(seg0 + (int64_t)item0 * KQ) + tid;
+    auto fetch = [&](int item0, float4_t (&pre)[PER4], float& preb) {
+        if constexpr (DENSE) {
+            // K1 == KQ: rows are contiguous; the last tile reads its missing rows from the table's last row (never counted)
 #pragma unroll
-            for (int p = 0; p < PER4; p++) pre[p] = src[256 * p];
-            preb = tid < NI ? (float)ev.col_b[item0 + tid] : 0.f;
+            for (int p = 0; p < PER4; p++) {
+                const int e4 = tid + 256 * p, it = (4 * e4) / KQ, k = (4 * e4) % KQ;
+                const int64_t j = (int64_t)item0 + it < I ? (int64_t)item0 + it : (int64_t)I - 1;
+                pre[p] = *reinterpret_cast<const float4_t*>(seg0 + j * KQ + k);
+            }
+            preb = (tid < NI && item0 + tid < I) ? (float)ev.col_b[item0 + tid] : 0.f;
             return;
         }
         preb = (tid < NI && item0 + tid < I) ? (float)ev.col_b[item0 + tid] : 0.f;
@@ -528,18 +538,18 @@ __global__ void __launch_bounds__(256, 2) score_screen_kernel(EvalDev ev, const 
                 if (K1 + K2 > 0) x = kk < K1 ? seg0[jc * K1 + kk] : seg1[jc * K2 + (kk - K1)];
                 v[c] = ok ? x : 0.f;
             }
-            pre[p] = make_float4(v[0], v[1], v[2], v[3]);
+            pre[p] = (float4_t){v[0], v[1], v[2], v[3]};
         }
     };
 
-    float4 pre[PER4]; float preb;
+    float4_t pre[PER4]; float preb;
     fetch(0, pre, preb);
     for (int item0 = 0; item0 < I; item0 += NI) {
         __syncthreads();
 #pragma unroll
         for (int p = 0; p < PER4; p++) {
             const int idx = 4 * (tid + 256 * p), it = idx / KQ, k = idx % KQ;
-            *reinterpret_cast<float4*>(&tile[it * STR + k]) = pre[p];
+            *reinterpret_cast<float4_t*>(&tile[it * STR + k]) = pre[p];
         }
         if (tid < NI) tile_b[tid] = preb;
         __syncthreads();
@@ -554,12 +564,11 @@ __global__ void __launch_bounds__(256, 2) score_screen_kernel(EvalDev ev, const 
             for (int mt = 0; mt < MT; mt++) acc[mt] = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c4 = 0; c4 < KC / 4; c4++) {
-                const float4 b4 = *reinterpret_cast<const float4*>(&tile[jj * STR + quad * KC + 4 * c4]);
-                const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+                const float4_t b4 = *reinterpret_cast<const float4_t*>(&tile[jj * STR + quad * KC + 4 * c4]);
 #pragma unroll
                 for (int c = 0; c < 4; c++)
 #pragma unroll
-                    for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][4 * c4 + c], bv[c], acc[mt], 0, 0, 0);
+                    for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][4 * c4 + c], b4[c], acc[mt], 0, 0, 0);
             }
             const float bj = tile_b[jj];
             unsigned open1 = 0, open2 = 0;   // bit (4 mt + r): that query's (second) threshold is within the margin of this column's score
@@ -567,17 +576,15 @@ __global__ void __launch_bounds__(256, 2) score_screen_kernel(EvalDev ev, const 
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int qi = qw + mt * 16 + 4 * quad + r;
-                    const float4 th = q_thr[qi]; const int2 ex = q_ex[qi];
                     const float sc = acc[mt][r] + bj;
-                    const int ok = (int)live & (int)(j != ex.x) & (int)(j != ex.y);
-                    const float d1 = th.x - sc;
-                    cnt[mt][r] += ok & (int)(d1 > th.z);
-                    open1 |= (unsigned)(ok & (int)(fabsf(d1) <= th.z)) << (4 * mt + r);
+                    const int ok = (int)live;
+                    const float d1 = th1[mt][r] - sc;
+                    cnt[mt][r] += ok & (int)(d1 > mar[mt][r]);
+                    open1 |= (unsigned)(ok & (int)(fabsf(d1) <= mar[mt][r])) << (4 * mt + r);
                     if (TWO) {
-                        const float d2 = th.y - sc;
-                        cnt2[mt][r] += ok & (int)(d2 > th.z);
-                        open2 |= (unsigned)(ok & (int)(fabsf(d2) <= th.z)) << (4 * mt + r);
+                        const float d2 = th2[mt][r] - sc;
+                        cnt2[mt][r] += ok & (int)(d2 > mar[mt][r]);
+                        open2 |= (unsigned)(ok & (int)(fabsf(d2) <= mar[mt][r])) << (4 * mt + r);
                     }
                 }
             // the rare ones: a compact loop, not unrolled
@@ -753,7 +760,8 @@ __global__ void __launch_bounds__(256) correct_clicked_kernel(DevModel m, EvalDe
         excluded += mult;
         if (e == test) test_clicked = true;
         if (e == val) val_clicked = true;
-        if (e == test || e == val || mult == 0) continue;   // the scoring kernel never counts the held-out pair
+        if (mult == 0) continue;
+        if ((e == test || e == val) && !ev.heldout_counted) continue;   // the fp64 sweeps never count the held-out pair
         double s = 0;
         if (m.model == REC_TRANSREC_L1) {
             for (int k = lane; k < K1; k += 64) s += fabs(q[k] - (double)seg0[(int64_t)e * K1 + k]);
@@ -768,6 +776,19 @@ __global__ void __launch_bounds__(256) correct_clicked_kernel(DevModel m, EvalDe
     }
     if (!test_clicked) excluded += ev.item_mult ? ev.item_mult[test] : 1;
     if (!val_clicked && val != test) excluded += ev.item_mult ? ev.item_mult[val] : 1;
+    if (ev.heldout_counted) {
+        // the screen counted the held-out items like any column: out again, unless the click list above already did it
+        for (int h = 0; h < 2; h++) {
+            const int e = h == 0 ? test : val;
+            if (e < 0 || (h == 0 ? test_clicked : (val_clicked || val == test))) continue;
+            double s = 0;
+            for (int k = lane; k < K1; k += 64) s += q[k] * (double)seg0[(int64_t)e * K1 + k];
+            for (int k = lane; k < K2; k += 64) s += q[K1 + k] * (double)seg1[(int64_t)e * K2 + k];
+            s = group_sum<64>(s) + ev.bconst[e];
+            c -= thr > s ? 1 : 0;
+            c2 -= thr2 > s ? 1 : 0;
+        }
+    }
     if (ev.amb) {
         // the columns the f32 screen left open, decided with the summation used for the clicked items above (a clicked
         // item among them is added here and taken out there by the same comparison)
@@ -852,7 +873,8 @@ static int launch_screen(const EvalDev& ev, const float* s0, const float* s1, in
 #define SCREEN_CASE(KQv)                                                                                        \
     case KQv: {                                                                                                 \
         const unsigned blocks = (unsigned)(ev.nq_pad / (4 * ScreenShape<KQv>::MT * 16));                        \
-        hipLaunchKernelGGL((score_screen_kernel<KQv, TWO>), dim3(blocks), dim3(256), 0, st, ev, s0, s1, qtest, qval, n_cols); \
+        if (ev.K1 == KQv) hipLaunchKernelGGL((score_screen_kernel<KQv, TWO, true>), dim3(blocks), dim3(256), 0, st, ev, s0, s1, qtest, qval, n_cols); \
+        else hipLaunchKernelGGL((score_screen_kernel<KQv, TWO, false>), dim3(blocks), dim3(256), 0, st, ev, s0, s1, qtest, qval, n_cols); \
         break;                                                                                                  \
     }
     switch (ev.KQ) {
@@ -980,6 +1002,7 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
     } else if (screen) {
         hipLaunchKernelGGL(screen_item_bounds_kernel, dim3(blocks_for_waves(I)), dim3(256), 0, st, ev, (const float*)seg0_cols, (const float*)seg1_cols, I, bounds);
         ev.tb_max = (const float*)bounds;
+        ev.heldout_counted = 1;
         hipLaunchKernelGGL(screen_margins_kernel, dim3(blocks_for_waves(ev.nq_pad)), dim3(256), 0, st, ev, (const unsigned*)bounds);
         rc = ev.nctx == 1 ? launch_screen<true>(ev, (const float*)seg0_cols, (const float*)seg1_cols, NC, qtest, qval, st)
                           : launch_screen<false>(ev, (const float*)seg0_cols, (const float*)seg1_cols, NC, qtest, qval, st);
@@ -1001,7 +1024,7 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
             for (int32_t x : open) g_screen_open += x;
         }
         if (over) {
-            ev.amb = nullptr;
+            ev.amb = nullptr; ev.heldout_counted = 0;
             rc = ev.nctx == 1 ? launch_score<T, true, false>(ev, seg0_cols, seg1_cols, NC, qtest, qval, st)
                               : launch_score<T, false, false>(ev, seg0_cols, seg1_cols, NC, qtest, qval, st);
             if (rc) { release(); return rc; }

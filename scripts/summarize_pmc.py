@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """rocprofv3 --pmc CSVs (one directory per pass) -> one JSON with the
 per-launch averages of the engine's kernels.  FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in
-KiB; they are converted to bytes here.  FETCH_SIZE under-reports wide (16 B per lane) streaming reads by
-2x on gfx950; the update kernel reads 4 B per lane, an access width for which the counter is not
-calibrated, so its value is kept as measured and flagged."""
+KiB; they are converted to bytes here.  On gfx950 FETCH_SIZE reports half the bytes of wide (16 B per lane) reads:
+kernels whose row reads are 16 B per lane (sgd_wide_kernel, score_screen_kernel on a table that fills the query width)
+get fetch_bytes_corrected = 2 x FETCH_SIZE and their traffic is computed from it; for the others (4 or 8 B per lane,
+an access width the counter is not calibrated for) the value is kept as measured and flagged."""
 import collections
 import csv
 import glob
@@ -16,7 +17,7 @@ for d in dirs:
     for f in glob.glob(d + "/*/*_counter_collection.csv") + glob.glob(d + "/*_counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-            if any(k in name for k in ("sgd_", "sampler_kernel", "score_count", "correct_clicked", "build_queries")):
+            if any(k in name for k in ("sgd_", "sampler_kernel", "score_count", "score_screen", "correct_clicked", "build_queries", "part_")):
                 agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for k, v in agg.items():
@@ -26,9 +27,13 @@ for k, v in agg.items():
         e["fetch_bytes"] = e["FETCH_SIZE"] * 1024
     if "WRITE_SIZE" in e:
         e["write_bytes"] = e["WRITE_SIZE"] * 1024
+    wide = "sgd_wide_kernel" in k or "score_screen_kernel" in k
+    if "fetch_bytes" in e and wide:
+        e["fetch_bytes_corrected"] = 2 * e["fetch_bytes"]
     if "fetch_bytes" in e and "write_bytes" in e:
-        e["hbm_traffic_bytes_per_launch"] = e["fetch_bytes"] + e["write_bytes"]
-        e["note"] = "FETCH_SIZE as measured (4 B per lane loads: uncalibrated width; x2 would be the upper bound); WRITE_SIZE includes float atomics"
+        e["hbm_traffic_bytes_per_launch"] = e.get("fetch_bytes_corrected", e["fetch_bytes"]) + e["write_bytes"]
+        e["note"] = ("16 B per lane reads: FETCH_SIZE doubled (gfx950 tallies their 128-B requests at 64 B); WRITE_SIZE includes float atomics" if wide else
+                     "FETCH_SIZE as measured (4 / 8 B per lane loads: uncalibrated width; x2 would be the upper bound); WRITE_SIZE includes float atomics")
     if "TCC_HIT_sum" in e and "TCC_MISS_sum" in e:
         e["l2_hit_rate"] = e["TCC_HIT_sum"] / (e["TCC_HIT_sum"] + e["TCC_MISS_sum"])
     res[k] = e
