@@ -187,13 +187,18 @@ int rec_num_tables(const rec_engine* e);
 int rec_table_info(const rec_engine* e, int t, void** dev_ptr, int64_t* rows, int64_t* cols, int* is_user_table);
 
 /* Tuning knobs (value 0/1 unless noted):
- *   "owner_neg"     BPRMF / MC / FPMC / PRME / HRM / TransRec: 1 = a launch of at least "owner_min" tuples is first
- *                   partitioned by the slice of the catalog its negative items lie in, and workgroup s of the update
+ *   "owner_neg"     BPRMF / MC / FPMC / PRME / HRM / TransRec, default 0: 1 = a launch of at least "owner_min" tuples is
+ *                   first partitioned by the slice of the catalog its negative items lie in, and workgroup s of the update
  *                   applies slice s, summing the negatives' deltas in LDS and moving a row's sum to memory with one
- *                   atomic row per "owner_flush" additions (default 8) instead of one per tuple.  Every tuple keeps the
- *                   reference's sampling (independent negatives).  Default 1 where "share_negative" 2 used to be:
- *                   epochs of >= 4M steps, not TransRec.
- *   "owner_flush", "owner_min"   see above (defaults 8 and 2^20)
+ *                   atomic row per "owner_flush" additions (default 8) instead of one per tuple.  Half the float atomics,
+ *                   but an item's steps in the negative's role then come late and out of order within a launch, which
+ *                   costs accuracy in proportion to the launch length: launches hold at most "owner_per_item" tuples
+ *                   per item of the catalog (default 8; test AUC -0.0035 after 3 epochs on a 1M-user x 200k-item corpus,
+ *                   -0.0006 at 1, -0.07 with one launch per epoch)
+ *   "owner_flush", "owner_min", "owner_per_item"   see above (defaults 8, 2^20 and 8)
+ *   "owner_slices"  slices of the catalog in owner mode: 0 (default) = the fewest of 256 / 512 / 1024 with which every
+ *                   item of a slice has its accumulator row in LDS; "part_tile" 0 / 4096 / 7168 = tuples the partition
+ *                   sorts in LDS at a time
  *   "wide"          1 (default) = f32 tables with K and KK multiples of 4 are updated by the form of the Hogwild kernel that
  *                   holds four consecutive components per lane (16-byte row accesses, four tuples per wave-instruction at
  *                   K = 64); 0 = always the one-dword-per-lane form (which also serves every other K, f64 and the shared

@@ -16,7 +16,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in dirs:
     for f in glob.glob(d + "/*/*_counter_collection.csv") + glob.glob(d + "/*_counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
             if any(k in name for k in ("sgd_", "sampler_kernel", "score_count", "score_screen", "correct_clicked", "build_queries", "part_")):
                 agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
