@@ -11,11 +11,12 @@ the two means has one of 0.0037 before any effect of the seed on the trajectory;
 the trajectory (what does not depend on which epoch validation happens to pick) - test AUC within 0.005, HIT@50 within
 max(0.006, range of the reference's seeds for the same mean).
 
-The history models are held to these bounds from below and to 0.01 from above: with the hybrid scatter (plain stores
+The history models are held to these bounds from below and to 0.015 from above: with the hybrid scatter (plain stores
 on user rows, biases and the hot items' rows) they end slightly ABOVE the reference on this corpus - Fossil /
 FossilSimple peak after 3-4 epochs and then overfit, and the updates a plain store loses on the most clicked rows
 slow that down (measured, means of 2 seeds against 3 reference seeds: Fossil best test AUC 0.7491 against 0.7459,
-trajectory HIT@50 0.2235 against 0.2184; REBUS best test AUC 0.7621 against 0.7567) - while with atomics on every row
+trajectory HIT@50 0.2235 against 0.2184, HIT@50 at the best checkpoint up to 0.2371 against 0.2235 from run to run; REBUS best
+test AUC 0.7621 against 0.7567) - while with atomics on every row
 ("update_policy" 0) they sit on the reference (REBUS 0.7560 / 0.7567) or just below it in the trajectory mean (Fossil
 0.7293 / 0.7348).  Pairs of tuples per history walk ("user_batch" 2) move neither by more than 0.002.
 Needs an MI355X."""
@@ -98,13 +99,13 @@ def test_shared_negatives_follow_the_reference(model):
 
 @pytest.mark.parametrize("model", HISTORY)
 def test_history_pairs_follow_the_reference(model):
-    _check(model, HISTORY_PAIRS, above=0.01)
+    _check(model, HISTORY_PAIRS, above=0.015)
 
 
 @pytest.mark.parametrize("model", ["Fossil", "REBUS"])
 def test_history_models_with_atomics_on_every_row_follow_the_reference(model):
     """Fossil's trajectory mean is allowed 0.007 below (measured 0.0055: it overfits a little faster after its peak)."""
-    _check(model, [("update_policy", 0), ("user_batch", 1)], traj_auc_slack=0.002 if model == "Fossil" else 0.0, above=0.01)
+    _check(model, [("update_policy", 0), ("user_batch", 1)], traj_auc_slack=0.002 if model == "Fossil" else 0.0, above=0.015)
 
 
 @pytest.mark.parametrize("model,world", [("BPRMF", 2), ("BPRMF", 4), ("FPMC", 4), ("TransRec", 2)])
