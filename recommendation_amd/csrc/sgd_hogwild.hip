@@ -130,7 +130,12 @@ __global__ void __launch_bounds__(OWNER ? OWNER_THREADS : 256) sgd_hogwild_kerne
     // different places, their CU shares its memory path with others), and with an equal share each the launch ends
     // with its slowest group.  Owner mode: one batch per claim from a counter in LDS; plain mode: CLAIM batches per
     // claim from a counter in memory (one returning atomic per 256 tuples).
-    constexpr int CLAIM = OWNER ? 1 : 64;
+    // batches per claim: 1 in owner mode (a counter in LDS), 64 per trip to the device counter in plain mode.  A launch too
+    // short to give every group a few claims of that size (ow.claim == 0) is split by stride instead: one claim per
+    // batch would put 100k returning atomics on one address (0.8 ms for 200k tuples).
+    const int CLAIM = OWNER ? 1 : ow.claim;
+    const int64_t stride_groups = (int64_t)gridDim.x * (blockDim.x / LPT);
+    int64_t stride_next = (int64_t)blockIdx.x * (blockDim.x / LPT) + threadIdx.x / LPT;
     __shared__ int lds_next;
     if constexpr (OWNER) {
         if (threadIdx.x == 0) lds_next = 0;
@@ -138,6 +143,7 @@ __global__ void __launch_bounds__(OWNER ? OWNER_THREADS : 256) sgd_hogwild_kerne
     }
     int64_t claim_cur = 0; int claim_left = 0;
     auto next_batch = [&]() -> int64_t {
+        if (!OWNER && CLAIM == 0) { const int64_t b = stride_next; stride_next += stride_groups; return b; }
         if (claim_left == 0) {
             int c = 0;
             if (g == 0) c = OWNER ? atomicAdd(&lds_next, CLAIM) : atomicAdd(m.work_counter, CLAIM);
@@ -398,7 +404,7 @@ template <int MODEL, class T>
 static int dispatch_shape(const DevModel& m, const int4* tuples, int64_t n, double lr, int atomic, const int64_t* qoff, int flush_at, hipStream_t st)
 {
     const int Kmax = m.K > m.KK ? m.K : m.KK;
-    OwnerArgs ow = {nullptr, 0, 0, 0, 1};
+    OwnerArgs ow = {nullptr, 0, 0, 0, 1, 64};
     size_t lds = 0;
     if (qoff) {
         ow.qoff = qoff; ow.slice_rows = sgd_owner_slice_rows(m); ow.flush_at = flush_at < 1 ? 1 : flush_at;
@@ -417,6 +423,8 @@ static int dispatch_shape(const DevModel& m, const int4* tuples, int64_t n, doub
         const int64_t groups_per_block = 256 / lpt;
         int64_t blocks = ((n + b - 1) / b + groups_per_block - 1) / groups_per_block;
         if (blocks > 2048) blocks = 2048;
+        // claims of 64 batches where every group gets at least four of them, a split by stride below that
+        ow.claim = ((n + b - 1) / b) >= 4 * 64 * blocks * groups_per_block ? 64 : 0;
         HIP_TRY(hipMemsetAsync(m.work_counter, 0, sizeof(int), st));   // the batch counter the groups claim from
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, m, tuples, n, (T)lr, atomic, ow);
         return 0;

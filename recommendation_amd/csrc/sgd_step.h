@@ -108,6 +108,7 @@ struct OwnerArgs {
     int rows_res;          // items of a slice with an accumulator row in LDS
     int acc_width;         // elements of an accumulator row (K, or K + KK)
     int flush_at;          // additions after which a row's accumulator is moved to memory
+    int claim;             // plain mode: batches a group takes from the launch's counter at a time
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -96,9 +96,15 @@ __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_ker
     }
 
     // claimed batches (see sgd_hogwild.hip)
-    constexpr int CLAIM = OWNER ? 1 : 64;
+    // batches per claim: 1 in owner mode (a counter in LDS), 64 per trip to the device counter in plain mode.  A launch too
+    // short to give every group a few claims of that size (ow.claim == 0) is split by stride instead: one claim per
+    // batch would put 100k returning atomics on one address (0.8 ms for 200k tuples).
+    const int CLAIM = OWNER ? 1 : ow.claim;
+    const int64_t stride_groups = (int64_t)gridDim.x * (blockDim.x / LPT);
+    int64_t stride_next = (int64_t)blockIdx.x * (blockDim.x / LPT) + threadIdx.x / LPT;
     int64_t claim_cur = 0; int claim_left = 0;
     auto next_batch = [&]() -> int64_t {
+        if (!OWNER && CLAIM == 0) { const int64_t b = stride_next; stride_next += stride_groups; return b; }
         if (claim_left == 0) {
             int c = 0;
             if (g == 0) c = OWNER ? atomicAdd(&lds_next, CLAIM) : atomicAdd(m.work_counter, CLAIM);
@@ -365,7 +371,7 @@ template <int MODEL>
 static int wide_dispatch(const DevModel& m, const int4* tuples, int64_t n, double lr, int atomic, const int64_t* qoff, int slices, int flush_at, hipStream_t st)
 {
     const int Kmax = m.K > m.KK ? m.K : m.KK;
-    OwnerArgs ow = {nullptr, 0, 0, 0, 1};
+    OwnerArgs ow = {nullptr, 0, 0, 0, 1, 64};
     auto go = [&](auto kern, auto kern_owner, int lpt, int b) -> int {
         if (qoff) {
             const size_t lds = wide_owner_layout(m, slices, ow);
@@ -377,6 +383,8 @@ static int wide_dispatch(const DevModel& m, const int4* tuples, int64_t n, doubl
         const int64_t groups_per_block = 256 / lpt;
         int64_t blocks = ((n + b - 1) / b + groups_per_block - 1) / groups_per_block;
         if (blocks > 2048) blocks = 2048;
+        // claims of 64 batches where every group gets at least four of them, a split by stride below that
+        ow.claim = ((n + b - 1) / b) >= 4 * 64 * blocks * groups_per_block ? 64 : 0;
         HIP_TRY(hipMemsetAsync(m.work_counter, 0, sizeof(int), st));   // the batch counter the groups claim from
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 4 * 1024, st, m, tuples, n, (float)lr, atomic, ow);
         return 0;
