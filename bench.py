@@ -495,7 +495,7 @@ def main():
         peak = FP32_MFMA_PEAK_TFLOPS if screened else FP64_MFMA_PEAK_TFLOPS
         out["eval"] = {"users_per_sec": round(n_eval / et, 1), "seconds": round(et, 4), "users": int(n_eval),
                        "auc_test": round(float(sums[1] / n_eval), 6), "hit50_test": round(float(sums[3] / n_eval), 6),
-                       "roofline": {"bound": "mfma", "kernel": "score_screen_kernel" if screened else "score_count_kernel",
+                       "roofline": {"bound": "mfma", "kernel": "score_screen_kernel" if screened else "score_count_l1_kernel" if args.model == "TransRec_L1" else "score_count_kernel",
                                     "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
                                     "dtype": "f32 sweep with a proven rounding margin, undecided columns in f64" if screened else "f64",
                                     "launch_ms": round(sc_ms, 3)}}

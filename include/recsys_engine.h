@@ -236,8 +236,8 @@ int rec_table_info(const rec_engine* e, int t, void** dev_ptr, int64_t* rows, in
  *   "eval_screen"   1 (default): with f32 tables the full-catalog sweep of rec_eval runs on the FP32 matrix pipe and decides
  *                   every comparison it can prove from a rounding bound; the columns within the bound of a threshold are
  *                   decided in fp64, so the counts are those of the fp64 sweep.  0: fp64 sweep.  (process-wide)
- *   "eval_screen_cap"  columns per query the screen may leave to fp64 (default 96); a query that needs more makes the
- *                   whole sweep run again in fp64
+ *   "eval_screen_cap"  columns per query the screen may leave to fp64 (default 0 = max(64, n_items / 2048)); a query that
+ *                   needs more makes the whole sweep run again in fp64
  *   "profile"       time every update / scoring / sampler launch with HIP events */
 int rec_set_option(rec_engine* e, const char* name, int64_t value);
 

@@ -453,11 +453,12 @@ __global__ void __launch_bounds__(256, 2) score_count_kernel(EvalDev ev, const T
 // with.  This kernel runs the same sweep on the FP32 matrix pipe (twice the rate, half the LDS bytes) and decides every
 // comparison it can PROVE: with u = 2^-24, q32 = fl(q'), and any order of accumulation,
 //     |fl32(b_j + <q32, T_j>) - (b_j + <q', T_j>)|  <=  (KQ + 2) u ||q'|| ||T_j||  +  u (|b_j| + |score|)
-// so a column whose f32 score differs from the f32 threshold by more than the query's margin
-//     M_q = 2 (KQ + 2) u ||q'|| Tmax + 4 u (Bmax + |thr| + ||q'|| Tmax)          (Tmax = max ||T_j||, Bmax = max |b_j|;
-// twice the bound, for an accumulator that truncates instead of rounding) is counted, or not, for certain.  The others -
-// a few dozen of 200k per query - go to the query's list and are decided in fp64 by correct_clicked_kernel with the very
-// summation it uses for the clicked items, so the counts are those of the fp64 sweep.
+// (the FP32 MFMA accumulates like a chain of fmaf, one rounding to nearest per term), so a column whose f32 score
+// differs from the f32 threshold by more than the query's margin
+//     M_q = 1.05 (KQ + 2) u ||q'|| Tmax + 4 u (Bmax + |thr| + ||q'|| Tmax)        (Tmax = max ||T_j||, Bmax = max |b_j|)
+// is counted, or not, for certain.  The others - a few of every 100k columns per query - go to the query's list and are
+// decided in fp64 by correct_clicked_kernel with the very summation it uses for the clicked items, so the counts are
+// those of the fp64 sweep.
 // v_mfma_f32_16x16x4_f32 operand maps: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
 // D[i = 4 (lane >> 4) + r][j = lane & 15] for result register r.  The contraction index is permuted so that quad
 // (lane >> 4) owns k = quad * KC .. quad * KC + KC - 1: its B values of an item are contiguous and come as ds_read_b128.
@@ -653,7 +654,7 @@ __global__ void __launch_bounds__(256) screen_margins_kernel(EvalDev ev, const u
         const double u = 5.9604644775390625e-08;
         const double t1 = ev.thr[w], t2 = ev.nctx == 1 ? ev.thr2[w] : 0.0;
         const double ta = (isfinite(t1) ? fabs(t1) : 0.0) + (isfinite(t2) ? fabs(t2) : 0.0);
-        const double mq = 2.0 * (ev.KQ + 2) * u * s * tmax + 4.0 * u * (bmax + ta + s * tmax) + 1e-30;
+        const double mq = 1.05 * (ev.KQ + 2) * u * s * tmax + 4.0 * u * (bmax + ta + s * tmax) + 1e-30;
         // a padding row (no query) decides nothing and lists nothing
         ev.qmar[w] = w < ev.nq ? __double2float_ru(mq * 1.000001) : 0.f;
     }
@@ -859,10 +860,10 @@ static int launch_score(const EvalDev& ev, const T* s0, const T* s1, int n_cols,
 
 static unsigned blocks_for_waves(int64_t waves) { return (unsigned)((waves * 64 + 255) / 256); }
 
-static int g_screen_on = 1, g_screen_cap = 96;
+static int g_screen_on = 1, g_screen_cap = 0;   // cap 0: by the size of the catalog (see eval_impl)
 static int g_screen_mode = 0;           // how the last full-catalog sweep ran: 0 fp64, 1 f32 screen, 2 screen overflowed and fp64 took over
 static int64_t g_screen_open = 0;       // columns the last screen left to fp64, over all queries
-void eval_configure_screen(int on, int cap) { if (on >= 0) g_screen_on = on; if (cap > 0) g_screen_cap = cap; }
+void eval_configure_screen(int on, int cap) { if (on >= 0) g_screen_on = on; if (cap >= 0) g_screen_cap = cap; }
 void eval_screen_stats(int* mode, int64_t* open) { *mode = g_screen_mode; *open = g_screen_open; }
 
 static int screen_qblock(int KQ) { return KQ <= 16 ? 256 : KQ <= 128 ? 128 : 64; }
@@ -985,7 +986,9 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
     unsigned* bounds = nullptr;
     if (!l1 && n_subset <= 0) { g_screen_mode = 0; g_screen_open = 0; }
     if (screen) {
-        ev.amb_cap = g_screen_cap;
+        // undecided columns per query grow with the catalog (margin x columns per unit of score): room for I / 2048 of them,
+        // at least 64, unless the caller has fixed it
+        ev.amb_cap = g_screen_cap > 0 ? g_screen_cap : std::max(64, ((I / 2048 + 31) / 32) * 32);
         EV_TRY(alloc((void**)&ev.qmar, sizeof(float) * ev.nq_pad));
         EV_TRY(alloc((void**)&ev.amb, sizeof(int32_t) * (size_t)ev.nq_pad * ev.amb_cap));
         EV_TRY(alloc((void**)&ev.amb_cnt, sizeof(int32_t) * ev.nq_pad));

@@ -124,13 +124,13 @@ def test_f32_screen_gives_the_counts_of_the_fp64_sweep(model, K):
         W = np.round(W * 8) / 8
         e.upload(W)
     got = {}
-    for name, opts in (("fp64", {"eval_screen": 0}), ("screen", {"eval_screen": 1, "eval_screen_cap": 96}), ("overflow", {"eval_screen_cap": 1})):
+    for name, opts in (("fp64", {"eval_screen": 0}), ("screen", {"eval_screen": 1, "eval_screen_cap": 1024}), ("overflow", {"eval_screen_cap": 1})):
         for k, v in opts.items():
             e.set_option(k, v)
         _, counts, _ = e.eval()
         open_cols, mode = e.kernel_stats(4)
         got[name] = (counts.copy(), mode, open_cols)
-    e.set_option("eval_screen_cap", 96)
+    e.set_option("eval_screen_cap", 0)
     assert got["fp64"][1] == 0 and got["screen"][1] == 1, [g[1:] for g in got.values()]
     # the tie-heavy grid overflows a list of one column for certain; random parameters may not
     assert got["overflow"][1] == 2 if model in ("BPRMF", "FPMC") else got["overflow"][1] in (1, 2), [g[1:] for g in got.values()]
