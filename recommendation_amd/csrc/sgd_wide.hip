@@ -381,10 +381,13 @@ static int wide_dispatch(const DevModel& m, const int4* tuples, int64_t n, doubl
             return 0;
         }
         const int64_t groups_per_block = 256 / lpt;
-        int64_t blocks = ((n + b - 1) / b + groups_per_block - 1) / groups_per_block;
+        // a short launch gets as many groups as give each about four batches (fewer tuples in flight at the same time, and
+        // so fewer steps computed from the same stale rows, than one batch per group), a long one the 2048 blocks the chip holds
+        const int64_t nbatch_h = (n + b - 1) / b;
+        int64_t blocks = (nbatch_h + 4 * groups_per_block - 1) / (4 * groups_per_block);
         if (blocks > 2048) blocks = 2048;
         // claims of 64 batches where every group gets at least four of them, a split by stride below that
-        ow.claim = ((n + b - 1) / b) >= 4 * 64 * blocks * groups_per_block ? 64 : 0;
+        ow.claim = nbatch_h >= 4 * 64 * blocks * groups_per_block ? 64 : 0;
         HIP_TRY(hipMemsetAsync(m.work_counter, 0, sizeof(int), st));   // the batch counter the groups claim from
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 4 * 1024, st, m, tuples, n, (float)lr, atomic, ow);
         return 0;

@@ -83,9 +83,16 @@ class ShardedTrainer:
     def steps_per_round(self):
         return self.eng.steps_per_epoch // (self.world * self.rounds)
 
+    def _torch_done(self):
+        # the engine launches on its own stream: what torch has queued on the tables must have finished before it goes on
+        if self.tabs and self.tabs[0].is_cuda:
+            import torch
+            torch.cuda.current_stream(self.tabs[0].device).synchronize()
+
     def begin_round(self):
         for t, b in zip(self.tabs, self.bases):
             b.copy_(t)
+        self._torch_done()
 
     def local_round(self, lr, seed, epoch, k):
         # a different tuple stream for every (epoch, round, rank)
@@ -98,6 +105,7 @@ class ShardedTrainer:
             # sum_r table_r, then base + scale * (sum - N * base)
             self.all_reduce_sum(t)
             t.sub_(b, alpha=float(self.world)).mul_(scale).add_(b)
+        self._torch_done()
 
     def epoch(self, lr, seed, epoch):
         for k in range(self.rounds):
