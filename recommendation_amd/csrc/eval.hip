@@ -491,14 +491,19 @@ __global__ void __launch_bounds__(256, DENSE && KQ <= 64 ? 3 : 2) score_screen_k
     for (int i = tid; i < QB; i += 256) q_amb[i] = 0;
     // thresholds and margin of this lane's 4 MT result rows (held-out items are counted like any column here and taken
     // out by correct_clicked_kernel: no per-element exclusion test)
-    float th1[MT][4], th2[MT][4], mar[MT][4];
+    // (one margin for the wavefront, the largest of its queries': a scalar instead of a register per result row)
+    float th1[MT][4], th2[MT][4], marw = 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int64_t qi = qblock + qw + mt * 16 + 4 * quad + r;
-            th1[mt][r] = (float)ev.thr[qi]; th2[mt][r] = TWO ? (float)ev.thr2[qi] : 0.f; mar[mt][r] = ev.qmar[qi];
+            th1[mt][r] = (float)ev.thr[qi]; th2[mt][r] = TWO ? (float)ev.thr2[qi] : 0.f; marw = fmaxf(marw, ev.qmar[qi]);
         }
+    // a NaN margin (NaN in the tables) must stay NaN - every comparison false, as in the fp64 sweep - so: max, not fmax
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float x = __shfl_xor(marw, o, 64); marw = (x > marw || x != x) ? x : marw; }
+    const float mar_w = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(marw)));
 
     float a[MT][KC];
 #pragma unroll
@@ -521,10 +526,10 @@ __global__ void __launch_bounds__(256, DENSE && KQ <= 64 ? 3 : 2) score_screen_k
                 const int64_t j = (int64_t)item0 + it < I ? (int64_t)item0 + it : (int64_t)I - 1;
                 pre[p] = *reinterpret_cast<const float4_t*>(seg0 + j * KQ + k);
             }
-            preb = (tid < NI && item0 + tid < I) ? (float)ev.col_b[item0 + tid] : 0.f;
+            preb = (tid < NI && item0 + tid < I) ? (float)ev.col_b[item0 + tid] : INFINITY;   // a column past the end scores +inf: never counted, never within a margin
             return;
         }
-        preb = (tid < NI && item0 + tid < I) ? (float)ev.col_b[item0 + tid] : 0.f;
+        preb = (tid < NI && item0 + tid < I) ? (float)ev.col_b[item0 + tid] : INFINITY;   // a column past the end scores +inf: never counted, never within a margin
 #pragma unroll
         for (int p = 0; p < PER4; p++) {
             float v[4];
@@ -559,7 +564,6 @@ __global__ void __launch_bounds__(256, DENSE && KQ <= 64 ? 3 : 2) score_screen_k
         for (int sub = 0; sub < NI / 16; sub++) {
             const int jj = sub * 16 + col;
             const int j = item0 + jj;
-            const bool live = j < I;
             float4_t acc[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) acc[mt] = (float4_t){0.f, 0.f, 0.f, 0.f};
@@ -572,21 +576,33 @@ __global__ void __launch_bounds__(256, DENSE && KQ <= 64 ? 3 : 2) score_screen_k
                     for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][4 * c4 + c], b4[c], acc[mt], 0, 0, 0);
             }
             const float bj = tile_b[jj];
+            // hot path: counts, and the smallest distance of any of this lane's scores to a threshold
+            float mind = INFINITY;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float sc = acc[mt][r] + bj;
+                    const float d1 = th1[mt][r] - sc;
+                    cnt[mt][r] += (int)(d1 > mar_w);
+                    if (TWO) {
+                        const float d2 = th2[mt][r] - sc;
+                        cnt2[mt][r] += (int)(d2 > mar_w);
+                        mind = __builtin_fminf(mind, __builtin_fminf(__builtin_fabsf(d1), __builtin_fabsf(d2)));
+                    } else {
+                        mind = __builtin_fminf(mind, __builtin_fabsf(d1));
+                    }
+                }
+            if (!__ballot(mind <= mar_w)) continue;
+            // some score of the wavefront lies within the margin of a threshold (one 16-item step in ten): which ones
             unsigned open1 = 0, open2 = 0;   // bit (4 mt + r): that query's (second) threshold is within the margin of this column's score
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const float sc = acc[mt][r] + bj;
-                    const int ok = (int)live;
-                    const float d1 = th1[mt][r] - sc;
-                    cnt[mt][r] += ok & (int)(d1 > mar[mt][r]);
-                    open1 |= (unsigned)(ok & (int)(fabsf(d1) <= mar[mt][r])) << (4 * mt + r);
-                    if (TWO) {
-                        const float d2 = th2[mt][r] - sc;
-                        cnt2[mt][r] += ok & (int)(d2 > mar[mt][r]);
-                        open2 |= (unsigned)(ok & (int)(fabsf(d2) <= mar[mt][r])) << (4 * mt + r);
-                    }
+                    open1 |= (unsigned)(__builtin_fabsf(th1[mt][r] - sc) <= mar_w) << (4 * mt + r);
+                    if (TWO) open2 |= (unsigned)(__builtin_fabsf(th2[mt][r] - sc) <= mar_w) << (4 * mt + r);
                 }
             // the rare ones: a compact loop, not unrolled
             unsigned open = open1 | open2;
