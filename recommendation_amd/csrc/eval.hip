@@ -751,12 +751,14 @@ static int launch_score_l1(const EvalDev& ev, const T* H, const int32_t* qtest, 
     return 0;
 }
 
-// Removes the clicked items from the counts and writes (count_val, count_test, max) per user.
-// One wavefront per query; the score of a clicked item is recomputed on the vector ALU.
+// Removes the clicked items from the counts, decides the columns the f32 screen left open, and writes (count_val,
+// count_test, max) per user.  One wavefront per query; the scores it needs are recomputed in fp64 on the vector ALU, four
+// items at a time (16 lanes per item) - ONE summation order for every use, so that a column added by one rule and taken out
+// by another is compared the same way both times.
 template <class T>
 __global__ void __launch_bounds__(256) correct_clicked_kernel(DevModel m, EvalDev ev)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, l16 = lane & 15, gq = lane >> 4;
     const int w = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (w >= ev.nq) return;
     const int u = m.eval_users[w / ev.nctx];
@@ -767,61 +769,62 @@ __global__ void __launch_bounds__(256) correct_clicked_kernel(DevModel m, EvalDe
     const T* seg0 = ev.seg0 >= 0 ? (const T*)m.tab[ev.seg0] : nullptr;
     const T* seg1 = ev.seg1 >= 0 ? (const T*)m.tab[ev.seg1] : nullptr;
     const int K1 = ev.K1, K2 = ev.K2;
+    const bool l1 = m.model == REC_TRANSREC_L1;
     const double thr = ev.thr[w], thr2 = ev.nctx == 1 ? ev.thr2[w] : 0.0;
-    int c = ev.cnt[w], c2 = ev.nctx == 1 ? ev.cnt2[w] : 0;
     // columns that are not candidates: every occurrence of a clicked item and of the held-out pair
-    int excluded = 0; bool test_clicked = false, val_clicked = false;
-    for (int i = 0; i < nc; i++) {
+    int excluded = 0; bool tc = false, vc = false;
+    for (int i = lane; i < nc; i += 64) {
         const int e = clk[i];
-        const int mult = ev.item_mult ? ev.item_mult[e] : 1;
-        excluded += mult;
-        if (e == test) test_clicked = true;
-        if (e == val) val_clicked = true;
-        if (mult == 0) continue;
-        if ((e == test || e == val) && !ev.heldout_counted) continue;   // the fp64 sweeps never count the held-out pair
-        double s = 0;
-        if (m.model == REC_TRANSREC_L1) {
-            for (int k = lane; k < K1; k += 64) s += fabs(q[k] - (double)seg0[(int64_t)e * K1 + k]);
-            s = -(ev.bconst[e] + group_sum<64>(s));
-        } else {
-            for (int k = lane; k < K1; k += 64) s += q[k] * (double)seg0[(int64_t)e * K1 + k];
-            for (int k = lane; k < K2; k += 64) s += q[K1 + k] * (double)seg1[(int64_t)e * K2 + k];
-            s = group_sum<64>(s) + ev.bconst[e];
-        }
-        c -= thr > s ? mult : 0;
-        c2 -= thr2 > s ? mult : 0;
+        excluded += ev.item_mult ? ev.item_mult[e] : 1;
+        tc |= e == test; vc |= e == val;
     }
+    excluded = group_sum<64>(excluded);
+    const bool test_clicked = __ballot(tc) != 0, val_clicked = __ballot(vc) != 0;
     if (!test_clicked) excluded += ev.item_mult ? ev.item_mult[test] : 1;
     if (!val_clicked && val != test) excluded += ev.item_mult ? ev.item_mult[val] : 1;
-    if (ev.heldout_counted) {
-        // the screen counted the held-out items like any column: out again, unless the click list above already did it
-        for (int h = 0; h < 2; h++) {
-            const int e = h == 0 ? test : val;
-            if (e < 0 || (h == 0 ? test_clicked : (val_clicked || val == test))) continue;
-            double s = 0;
-            for (int k = lane; k < K1; k += 64) s += q[k] * (double)seg0[(int64_t)e * K1 + k];
-            for (int k = lane; k < K2; k += 64) s += q[K1 + k] * (double)seg1[(int64_t)e * K2 + k];
-            s = group_sum<64>(s) + ev.bconst[e];
-            c -= thr > s ? 1 : 0;
-            c2 -= thr2 > s ? 1 : 0;
+
+    // one list of (item, weight, thresholds it applies to): the clicked items (-multiplicity; the fp64 sweeps never count
+    // the held-out pair, the screen counts it like any column), then the held-out pair where the screen counted it and
+    // the click list does not take it out, then the columns the screen left open (+1 where the threshold is above the score)
+    const int na = ev.amb ? (ev.amb_cnt[w] < ev.amb_cap ? ev.amb_cnt[w] : ev.amb_cap) : 0;
+    const int32_t* open = ev.amb ? ev.amb + (int64_t)w * ev.amb_cap : nullptr;
+    const int total = nc + 2 + na;
+    int dc = 0, dc2 = 0;
+    for (int base = 0; base < total; base += 4) {
+        const int idx = base + gq;
+        int e = -1, wgt = 0, which = 3;
+        if (idx < nc) {
+            e = clk[idx];
+            wgt = -(ev.item_mult ? ev.item_mult[e] : 1);
+            if ((e == test || e == val) && !ev.heldout_counted) wgt = 0;
+        } else if (idx < nc + 2) {
+            const int h = idx - nc;
+            e = h == 0 ? test : val;
+            const bool done = h == 0 ? test_clicked : (val_clicked || val == test);
+            wgt = (ev.heldout_counted && e >= 0 && !done) ? -1 : 0;
+        } else if (idx < total) {
+            const int ent = open[idx - nc - 2];
+            e = ent & 0x0fffffff; which = ent >> 28; wgt = 1;
         }
-    }
-    if (ev.amb) {
-        // the columns the f32 screen left open, decided with the summation used for the clicked items above (a clicked
-        // item among them is added here and taken out there by the same comparison)
-        const int na = ev.amb_cnt[w] < ev.amb_cap ? ev.amb_cnt[w] : ev.amb_cap;
-        const int32_t* list = ev.amb + (int64_t)w * ev.amb_cap;
-        for (int i = 0; i < na; i++) {
-            const int ent = list[i], e = ent & 0x0fffffff, which = ent >> 28;
-            double s = 0;
-            for (int k = lane; k < K1; k += 64) s += q[k] * (double)seg0[(int64_t)e * K1 + k];
-            for (int k = lane; k < K2; k += 64) s += q[K1 + k] * (double)seg1[(int64_t)e * K2 + k];
-            s = group_sum<64>(s) + ev.bconst[e];
-            c += ((which & 1) && thr > s) ? 1 : 0;
-            c2 += ((which & 2) && thr2 > s) ? 1 : 0;
+        if (!__ballot(wgt != 0)) continue;
+        const int64_t ec = (wgt != 0 && e >= 0) ? e : 0;   // a group without work still runs the loads, on item 0
+        double s = 0;
+        if (l1) {
+            for (int k = l16; k < K1; k += 16) s += fabs(q[k] - (double)seg0[ec * K1 + k]);
+            s = -(ev.bconst[ec] + group_sum<16>(s));
+        } else {
+            for (int k = l16; k < K1; k += 16) s += q[k] * (double)seg0[ec * K1 + k];
+            for (int k = l16; k < K2; k += 16) s += q[K1 + k] * (double)seg1[ec * K2 + k];
+            s = group_sum<16>(s) + ev.bconst[ec];
         }
+        dc += ((which & 1) && thr > s) ? wgt : 0;
+        dc2 += ((which & 2) && thr2 > s) ? wgt : 0;
     }
+    // every lane of a group holds the group's sum: add the four groups
+    dc = dc + __shfl_xor(dc, 16, 64); dc = dc + __shfl_xor(dc, 32, 64);
+    dc2 = dc2 + __shfl_xor(dc2, 16, 64); dc2 = dc2 + __shfl_xor(dc2, 32, 64);
     if (lane == 0) {
+        const int c = ev.cnt[w] + dc, c2 = (ev.nctx == 1 ? ev.cnt2[w] : 0) + dc2;
         if (ev.nctx == 1) {
             ev.counts[3 * (int64_t)u] = c; ev.counts[3 * (int64_t)u + 1] = c2;
         } else {
