@@ -465,8 +465,8 @@ __global__ void __launch_bounds__(256, 2) score_count_kernel(EvalDev ev, const T
 typedef float float4_t __attribute__((ext_vector_type(4)));
 
 template <int KQ, bool DENSE = false> struct ScreenShape {
-    // items per tile; twice as many when the table fills the query width (a tile is one contiguous run, fetched without
-    // the address arithmetic of the general case, whose registers the larger tile needs)
+    // items per tile; twice as many when the table segments fill the query width in 16-byte pieces (fetched without the
+    // per-element address arithmetic of the general case, whose registers the larger tile needs)
     static constexpr int NI = (KQ <= 64 ? 64 : KQ <= 128 ? 32 : 16) * (DENSE ? 2 : 1);
     static constexpr int MT = KQ <= 16 ? 4 : KQ <= 128 ? 2 : 1;       // 16-query tiles per wavefront
 };
@@ -519,12 +519,14 @@ __global__ void __launch_bounds__(256, DENSE && KQ <= 64 ? 3 : 2) score_screen_k
 
     auto fetch = [&](int item0, float4_t (&pre)[PER4], float& preb) {
         if constexpr (DENSE) {
-            // K1 == KQ: rows are contiguous; the last tile reads its missing rows from the table's last row (never counted)
+            // K1 + K2 == KQ, both multiples of 4: a row is one run of 16-byte pieces (or one per table segment); the last
+            // tile reads its missing rows from the tables' last row (never counted)
 #pragma unroll
             for (int p = 0; p < PER4; p++) {
                 const int e4 = tid + 256 * p, it = (4 * e4) / KQ, k = (4 * e4) % KQ;
                 const int64_t j = (int64_t)item0 + it < I ? (int64_t)item0 + it : (int64_t)I - 1;
-                pre[p] = *reinterpret_cast<const float4_t*>(seg0 + j * KQ + k);
+                const float* src = k < K1 ? seg0 + j * K1 + k : seg1 + j * K2 + (k - K1);
+                pre[p] = *reinterpret_cast<const float4_t*>(src);
             }
             preb = (tid < NI && item0 + tid < I) ? (float)ev.col_b[item0 + tid] : INFINITY;   // a column past the end scores +inf: never counted, never within a margin
             return;
@@ -893,7 +895,7 @@ static int launch_screen(const EvalDev& ev, const float* s0, const float* s1, in
 #define SCREEN_CASE(KQv)                                                                                        \
     case KQv: {                                                                                                 \
         const unsigned blocks = (unsigned)(ev.nq_pad / (4 * ScreenShape<KQv>::MT * 16));                        \
-        if (ev.K1 == KQv) hipLaunchKernelGGL((score_screen_kernel<KQv, TWO, true>), dim3(blocks), dim3(256), 0, st, ev, s0, s1, qtest, qval, n_cols); \
+        if (ev.K1 + ev.K2 == KQv && ev.K1 % 4 == 0 && ev.K2 % 4 == 0) hipLaunchKernelGGL((score_screen_kernel<KQv, TWO, true>), dim3(blocks), dim3(256), 0, st, ev, s0, s1, qtest, qval, n_cols); \
         else hipLaunchKernelGGL((score_screen_kernel<KQv, TWO, false>), dim3(blocks), dim3(256), 0, st, ev, s0, s1, qtest, qval, n_cols); \
         break;                                                                                                  \
     }
