@@ -435,17 +435,8 @@ def main():
     main_res = measure(eng, mode, args.precision, args.steps, args.warmup, trainer)
     roofline = main_res["roofline"]
     roofline["tuples_drawn_over_expected"] = round(eng.tuples_drawn / max(1, my_steps * (args.steps + args.warmup)), 6)
-    # HBM-side bytes per launch of the same kernel on the same workload from the committed counter passes (rocprofv3 --pmc
-    # FETCH_SIZE / WRITE_SIZE in separate runs, KiB -> bytes, FETCH_SIZE doubled for 16-byte-per-lane reads:
-    # scripts/collect_profiles.sh + summarize_pmc.py); null for workloads that were not profiled
-    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r02_{args.model}_pmc_summary.json")
-    default_shape = (args.users, args.items, args.clicks, args.k) == (1_000_000, 200_000, 100_000_000, 64) and world == 1 and args.precision == "f32"
-    untouched = args.policy < 0 and args.owner < 0 and args.share_negative == 0 and args.share_positive == 0 and args.group < 0 and args.wide < 0 and args.atomic_mask < 0
-    if default_shape and untouched and os.path.exists(prof):
-        for name, rec in json.load(open(prof)).items():
-            if name.startswith(roofline["kernel"]) and "hbm_traffic_bytes_per_launch" in rec:
-                roofline["traffic"] = int(rec["hbm_traffic_bytes_per_launch"])
-                roofline["traffic_source"] = f"profiles/r02_{args.model}_pmc_summary.json ({name}, {rec['launches_seen']} launches)"
+    # (roofline.traffic stays null: the HBM-side counters need rocprofv3 around the process; what they read for this
+    # command is in profiles/, collected by scripts/collect_profiles.sh)
     # practical ceiling: a device-to-device copy of 1 GiB (read + write counted)
     src = torch.empty(1 << 28, dtype=torch.float32, device=dev); dst = torch.empty_like(src)
     dst.copy_(src); torch.cuda.synchronize()

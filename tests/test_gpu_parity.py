@@ -662,6 +662,17 @@ def _traj_groups():
     return groups
 
 
+def _check_hit50(key, refs, got):
+    """HIT@50 on the test item at the best-validation checkpoint: the mean of the engine's runs within max(0.015, the
+    spread of the reference's own srand seeds) of the mean of the reference's distinct runs (srand(0) and srand(1) give
+    the same run in glibc).  6040 users: one evaluation has a standard error of 0.005, the checkpoint validation picks
+    moves it by more (the reference's seeds differ by up to 0.018, Fossil)."""
+    ref_hits = sorted({round(r["hit50_test_at_best"], 6) for r in refs})
+    hit, ref_hit = np.mean([g["hit50_test_at_best"] for g in got]), np.mean(ref_hits)
+    print(key, "hit50 engine %.4f reference %.4f (%s)" % (hit, ref_hit, ref_hits))
+    assert abs(hit - ref_hit) <= max(0.015, ref_hits[-1] - ref_hits[0]), (key, hit, ref_hits)
+
+
 @pytest.mark.parametrize("key", sorted(_traj_groups()))
 def test_converged_auc_within_0_005_of_reference(key):
     """Criterion (c).  Reference side: its own oneiteration + AUC on ML-5 (K=10), best-validation
@@ -676,6 +687,7 @@ def test_converged_auc_within_0_005_of_reference(key):
     val_auc = np.mean([g["best_auc_val"] for g in got])
     assert abs(test_auc - ref_test) <= 0.005, (key, test_auc, ref_test)
     assert abs(val_auc - ref_val) <= 0.005, (key, val_auc, ref_val)
+    _check_hit50(key, refs, got)
 
 
 _SHARED_NEG_KEYS = [k for k in sorted(_traj_groups()) if k[0] in ("BPRMF", "MC", "FPMC", "PRME", "HRM_avg", "HRM_max")]
@@ -696,6 +708,7 @@ def test_converged_auc_with_shared_negatives_within_0_005_of_reference(key):
     val_auc = np.mean([g["best_auc_val"] for g in got])
     assert abs(test_auc - ref_test) <= 0.005, (key, test_auc, ref_test)
     assert abs(val_auc - ref_val) <= 0.005, (key, val_auc, ref_val)
+    _check_hit50(key, refs, got)
 
 
 @pytest.mark.parametrize("model", ["BPRMF", "FPMC", "TransRec", "REBUS"])
