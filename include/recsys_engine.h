@@ -219,8 +219,9 @@ int rec_table_info(const rec_engine* e, int t, void** dev_ptr, int64_t* rows, in
  *                   shuffled inside a range (experiment knob: how much item locality in time the SGD tolerates)
  *   "share_negative" BPRMF / MC / FPMC / PRME / HRM / TransRec: 2 (or 4) = that many consecutive steps of an epoch take their negative from one
  *                   stream of candidates (each accepting the first one its own tuple allows, so nearly always the same item)
- *                   and the update scatters that item's rows once for all of them (default 2 when an epoch is >= 4M steps, TransRec and smaller
- *                   epochs 1).  Measured: 1.25x the throughput, test AUC within 0.001, HIT@50 1-3 % lower (relative); 1 = independent draws
+ *                   and the update scatters that item's rows once for all of them.  Default 1 = independent draws, the reference's sampling.
+ *                   Measured for 2: 1.2x the throughput, test AUC 0.002-0.003 lower after the first epochs of a 100M-interaction
+ *                   corpus, HIT@50 1-3 % lower (relative)
  *   "share_positive" BPRMF / MC / FPMC / PRME / HRM: 2 = step 2p+1 of an epoch is another event of step 2p's positive item, drawn
  *                   with the events' own weights (every step keeps the reference's distribution; the two share the positive and
  *                   the negative, and the update scatters both items' rows once).  Default 1.  Measured: 1.15x the throughput
