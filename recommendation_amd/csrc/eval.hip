@@ -42,7 +42,6 @@ struct EvalDev {
     int32_t* amb_cnt;          // [nq_pad] how many (may exceed amb_cap: then *amb_overflow is set and the lists are not used)
     int amb_cap;
     int32_t* amb_overflow;
-    const float* tb_max;       // [2] max_j ||T_j||_2 and max_j |b_j|, rounded up
     int heldout_counted;       // 1: the sweep counted the test / validation items like any column (the screen does): taken out afterwards
 };
 
@@ -1025,7 +1024,6 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
         rc = launch_score_l1<T, false>(ev, seg0_cols, qtest, qval, NC, m.K, st);
     } else if (screen) {
         hipLaunchKernelGGL(screen_item_bounds_kernel, dim3(blocks_for_waves(I)), dim3(256), 0, st, ev, (const float*)seg0_cols, (const float*)seg1_cols, I, bounds);
-        ev.tb_max = (const float*)bounds;
         ev.heldout_counted = 1;
         hipLaunchKernelGGL(screen_margins_kernel, dim3(blocks_for_waves(ev.nq_pad)), dim3(256), 0, st, ev, (const unsigned*)bounds);
         rc = ev.nctx == 1 ? launch_screen<true>(ev, (const float*)seg0_cols, (const float*)seg1_cols, NC, qtest, qval, st)

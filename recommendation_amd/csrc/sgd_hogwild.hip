@@ -45,9 +45,6 @@ __global__ void __launch_bounds__(OWNER ? OWNER_THREADS : 256) sgd_hogwild_kerne
     T* acc = (T*)owner_lds;                                                        // [rows_res][acc_width]
     unsigned* pend = (unsigned*)(owner_lds + (size_t)ow.rows_res * ow.acc_width * sizeof(T));   // [rows_res] additions since the last flush
     const int slice_base = OWNER ? (int)blockIdx.x * ow.slice_rows : 0;
-#ifdef OWNER_STAMPS
-    const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();
-#endif
     if constexpr (OWNER) {
         const int64_t q0 = ow.qoff[blockIdx.x];
         tuples += q0; n = ow.qoff[blockIdx.x + 1] - q0;
@@ -315,16 +312,7 @@ __global__ void __launch_bounds__(OWNER ? OWNER_THREADS : 256) sgd_hogwild_kerne
 
     if constexpr (OWNER) {
         // what is still pending goes to memory: one group per accumulator row
-#ifdef OWNER_STAMPS
-        const unsigned long long stamp_w = __builtin_amdgcn_s_memrealtime();
-#endif
         __syncthreads();
-#ifdef OWNER_STAMPS
-        if ((threadIdx.x & 63) == 0) {
-            unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            printf("STAMP %d %d %d %llu %llu %llu %lld\n", (int)blockIdx.x, (int)(threadIdx.x >> 6), (int)(xcc & 15), stamp0, stamp_w, (unsigned long long)__builtin_amdgcn_s_memrealtime(), (long long)n);
-        }
-#endif
         for (int sl = (int)gid; sl < ow.rows_res; sl += (int)ngroups) {
             if (pend[sl] == 0) continue;
             const int4 t = (MODEL == REC_BPRMF || MODEL == REC_MC) ? make_int4(0, 0, slice_base + sl, 0) : make_int4(0, 0, 0, slice_base + sl);
