@@ -100,8 +100,10 @@ __device__ __forceinline__ void walk_history(T* tab, const int32_t* seq, const u
     }
 }
 
+// (f32, K <= 64, one or two tuples per walk: held to 128 registers, four wavefronts per SIMD - REBUS with two tuples per
+// walk would take 137 and run at three: 102 -> 121 M triples/s on the 1M-user corpus for 7 spilled registers)
 template <int MODEL, class T, int EPL, int G>
-__global__ void __launch_bounds__(256) sgd_history_batch_kernel(DevModel m, const int4* __restrict__ tuples, int64_t n, T lr, int atomic, int CLAIM)
+__global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 4 : 1) sgd_history_batch_kernel(DevModel m, const int4* __restrict__ tuples, int64_t n, T lr, int atomic, int CLAIM)
 {
     constexpr int RIF = EPL == 1 ? 8 : 4;   // history rows per round
     const int lane = threadIdx.x & 63;
