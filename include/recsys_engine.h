@@ -144,10 +144,19 @@ int64_t rec_steps_per_epoch(const rec_engine* e);
  * evaluated).  xpos_out (optional): per user x_test, x_val. */
 int rec_eval(rec_engine* e, int topn, rec_metrics* out, int32_t* counts_out, double* xpos_out);
 
-/* replaces: model::sampleAUC / Fossil::sampleAUC / REBUS::sampleAUC (src/model.cpp:100-167): the validation estimate
- * over n_sampled candidate draws instead of the whole catalog (the reference draws 2000 per user from the global
- * rand() stream; here one draw of n_sampled items, with replacement, is shared by all users - the same estimator
- * of the mean, computed by the same kernels on gathered item rows).  Draws that hit a clicked or held-out item are
+/* replaces: model::sampleAUC / Fossil::sampleAUC / REBUS::sampleAUC (src/model.cpp:100-167, Fossil.cpp:480-564,
+ * REBUS.cpp:625-730) with the reference's sampling: n_sampled candidate draws PER USER (the reference: 2000 from the
+ * global rand() stream; here draw d of user u is a counter-based hash of (seed, u, d), uniform over the catalog, with
+ * replacement).  A draw that hits a clicked or held-out item is skipped, not replaced (max <= n_sampled); the others
+ * are compared under the validation and under the test context.  One wavefront per user gathers and scores its own
+ * draws in fp64.  counts_out (optional): as rec_eval, max = the user's number of valid draws (users whose draws were all
+ * skipped: -1,-1,-1 and left out of the means).  draws_out (optional): [n_users][n_sampled] the item of every draw
+ * (-1 in rows of users that are not evaluated). */
+int rec_eval_sampled_per_user(rec_engine* e, int topn, int32_t n_sampled, uint64_t seed, rec_metrics* out, int32_t* counts_out,
+                              int32_t* draws_out);
+
+/* The same estimate from ONE draw of n_sampled items, with replacement, shared by all users - computed by the kernels of
+ * rec_eval on gathered item rows.  Its mean is the same; its item-sampling error does not average out over users.  Draws that hit a clicked or held-out item are
  * skipped, not replaced (max <= n_sampled), as in the reference.  counts_out (optional): as rec_eval;
  * sampled_out (optional): the n_sampled item ids. */
 int rec_eval_sampled(rec_engine* e, int topn, int32_t n_sampled, uint64_t seed, rec_metrics* out, int32_t* counts_out,

@@ -162,9 +162,16 @@ static void finish_simple(M& md)
 // the model's own AUC() every C epochs; prints "EPOCH iter seconds" after every epoch and
 // "TRAJ iter AUC_val AUC_test HIT_val HIT_test" and "EVALSEC iter seconds" (the time of that AUC() call) after every
 // evaluation.
-static int g_traj_n = 0, g_traj_c = 0;
+// "sauc:N" in the same place: N calls of the model's own sampleAUC() on the loaded parameters (2000 rand() draws
+// per user each, model.cpp:100-167); prints "SAUC call AUC_val AUC_test var".
+static int g_traj_n = 0, g_traj_c = 0, g_sauc_n = 0;
 #define TRAJ(md, EPOCH_CALL)                                                                  \
 	do {                                                                                      \
+		for (int sc = 0; sc < g_sauc_n; sc++) {                                               \
+			double a_, b_, c_; md.sampleAUC(&a_, &b_, &c_);                                   \
+			fprintf(stderr, "SAUC %d %.9f %.9f %.9f\n", sc, a_, b_, c_);                      \
+		}                                                                                     \
+		if (g_sauc_n) break;                                                                  \
 		for (int it = 1; it <= g_traj_n; it++) {                                              \
 			const auto t0_ = std::chrono::steady_clock::now();                                \
 			md.EPOCH_CALL(lr);                                                                \
@@ -184,6 +191,7 @@ int main(int argc, char** argv)
 {
 	if (argc != 14) { fprintf(stderr, "bad usage\n"); return 2; }
 	if (strncmp(argv[11], "traj:", 5) == 0) { sscanf(argv[11], "traj:%d:%d", &g_traj_n, &g_traj_c); argv[11] = (char*)"-"; }
+	if (strncmp(argv[11], "sauc:", 5) == 0) { sscanf(argv[11], "sauc:%d", &g_sauc_n); g_traj_n = 1; g_traj_c = 1; argv[11] = (char*)"-"; }
 	string name = argv[1];
 	const char* data_path = argv[2];
 	int K = atoi(argv[3]);

@@ -14,7 +14,7 @@ SEQUENTIAL, HOGWILD = 0, 1
 
 EXPORTS = ["rec_last_error", "rec_create", "rec_destroy", "rec_sync", "rec_nw", "rec_params_upload",
            "rec_params_download", "rec_params_read", "rec_params_init", "rec_snapshot_best", "rec_restore_best", "rec_sgd_replay", "rec_sgd_replay_static", "rec_partition_tuples", "rec_owner_slices",
-           "rec_sgd_epoch", "rec_sample_tuples", "rec_sample_events", "rec_tuples_drawn", "rec_steps_per_epoch", "rec_eval", "rec_eval_sampled", "rec_eval_topk", "rec_eval_sums",
+           "rec_sgd_epoch", "rec_sample_tuples", "rec_sample_events", "rec_tuples_drawn", "rec_steps_per_epoch", "rec_eval", "rec_eval_sampled", "rec_eval_sampled_per_user", "rec_eval_topk", "rec_eval_sums",
            "rec_rebus_build_paths", "rec_fsub_mine", "rec_num_tables", "rec_table_info", "rec_set_option", "rec_kernel_stats"]
 
 
@@ -228,6 +228,15 @@ class Engine:
         _check(lib().rec_eval_sampled(self.handle, C.c_int(topn), C.c_int32(n_sampled), C.c_uint64(seed), C.byref(m), _p(counts),
                                       _p(sampled)))
         return m, counts, sampled
+
+    def eval_sampled_per_user(self, n_sampled=2000, seed=0, topn=50, want_draws=False):
+        """model::sampleAUC with the reference's sampling: n_sampled candidate draws per user."""
+        m = Metrics()
+        counts = np.zeros((self.n_users, 3), np.int32)
+        draws = np.zeros((self.n_users, n_sampled), np.int32) if want_draws else None
+        _check(lib().rec_eval_sampled_per_user(self.handle, C.c_int(topn), C.c_int32(n_sampled), C.c_uint64(seed), C.byref(m),
+                                               _p(counts), _p(draws)))
+        return m, counts, draws
 
     def eval_topk(self, users, k=50):
         users = np.ascontiguousarray(users, np.int32)

@@ -140,11 +140,14 @@ int launch_event_sampler(const DevModel& m, int4* tuples, int64_t cap, int64_t n
 // listed in subset_host (host memory, repetitions allowed: every occurrence is one scored candidate).
 // counts_host: [U][3] (count_val, count_test, max; -1 for users not evaluated); xpos_host (optional): [U][2]
 // (x_test, x_val).
+// user_draws > 0: instead of a sweep, every user is scored against user_draws candidate draws of its own (keyed by
+// draw_seed, the user and the draw index; draws_host, optional, [U][user_draws] receives them, -1 for users not evaluated).
 // f32 screen of the full-catalog sweep (f32 tables): on (1) / off (0) / unchanged (-1); columns a query may leave to fp64 (cap > 0)
 void eval_configure_screen(int on, int cap);
 void eval_screen_stats(int* mode, int64_t* open);   // of the last full-catalog sweep: 0 fp64 / 1 screen / 2 screen overflowed; undecided columns ("profile" on)
 int eval_run(const DevModel& m, int precision, int32_t* counts_host, double* xpos_host, hipStream_t st,
-             double* score_ms, int64_t* score_launches, bool profile, const int32_t* subset_host, int n_subset);
+             double* score_ms, int64_t* score_launches, bool profile, const int32_t* subset_host, int n_subset,
+             int user_draws = 0, uint64_t draw_seed = 0, int32_t* draws_host = nullptr);
 
 // The k best-scored items of the validation and of the test context of every listed user:
 // items_host / scores_host are [n_users][2][k] (context 0 = validation, 1 = test; -1 / -inf past the end).

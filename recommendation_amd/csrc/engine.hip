@@ -937,12 +937,14 @@ static void reduce_metrics(const rec_engine* e, const int32_t* counts, int topn,
     }
 }
 
-static int eval_counts(rec_engine* e, std::vector<int32_t>& counts, double* xpos, const int32_t* subset = nullptr, int n_subset = 0)
+static int eval_counts(rec_engine* e, std::vector<int32_t>& counts, double* xpos, const int32_t* subset = nullptr, int n_subset = 0,
+                       int user_draws = 0, uint64_t draw_seed = 0, int32_t* draws = nullptr)
 {
     ENG_HIP(hipSetDevice(e->desc.device));
     ENG_HIP(hipStreamSynchronize(e->st));
     counts.resize((size_t)e->U * 3);
-    return eval_run(e->dm, e->desc.precision, counts.data(), xpos, e->st, &e->ms[1], &e->launches[1], e->profile != 0, subset, n_subset);
+    return eval_run(e->dm, e->desc.precision, counts.data(), xpos, e->st, &e->ms[1], &e->launches[1], e->profile != 0, subset, n_subset,
+                    user_draws, draw_seed, draws);
 }
 
 static void metrics_from_counts(const rec_engine* e, const std::vector<int32_t>& counts, int topn, rec_metrics* out)
@@ -985,6 +987,22 @@ extern "C" int rec_eval_sampled(rec_engine* e, int topn, int32_t n_sampled, uint
     metrics_from_counts(e, counts, topn, out);
     if (counts_out) memcpy(counts_out, counts.data(), sizeof(int32_t) * counts.size());
     if (sampled_out) memcpy(sampled_out, sub.data(), sizeof(int32_t) * sub.size());
+    return 0;
+}
+
+extern "C" int rec_eval_sampled_per_user(rec_engine* e, int topn, int32_t n_sampled, uint64_t seed, rec_metrics* out, int32_t* counts_out,
+                                         int32_t* draws_out)
+{
+    if (!e || !out) { rec_set_error("null argument"); return -1; }
+    if (n_sampled < 1 || n_sampled > (1 << 20)) { rec_set_error("n_sampled must be in 1..2^20"); return -1; }
+    if (draws_out && (int64_t)e->U * n_sampled > ((int64_t)1 << 31)) { rec_set_error("draws_out: more than 2^31 draws; pass NULL"); return -1; }
+    std::vector<int32_t> counts;
+    if (int rc = eval_counts(e, counts, nullptr, nullptr, 0, n_sampled, seed, draws_out)) return rc;
+    // a user whose draws were all skipped has no estimate (the reference divides by max = 0 there): left out
+    for (int u = 0; u < e->U; u++)
+        if (counts[3 * (size_t)u + 2] == 0) counts[3 * (size_t)u] = counts[3 * (size_t)u + 1] = counts[3 * (size_t)u + 2] = -1;
+    metrics_from_counts(e, counts, topn, out);
+    if (counts_out) memcpy(counts_out, counts.data(), sizeof(int32_t) * counts.size());
     return 0;
 }
 

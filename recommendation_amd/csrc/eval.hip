@@ -835,6 +835,73 @@ __global__ void __launch_bounds__(256) correct_clicked_kernel(DevModel m, EvalDe
     }
 }
 
+// Candidate draw d of user u: what model::sampleAUC takes from rand() % nItems (model.cpp:122-123), from a counter-based
+// hash instead (splitmix64 finaliser), so that a user's draws depend on (seed, user, draw) alone.
+__host__ __device__ __forceinline__ uint64_t draw_mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__host__ __device__ __forceinline__ int32_t user_draw(uint64_t seed, int u, int d, int n_items)
+{
+    const uint64_t z = draw_mix64(draw_mix64(seed ^ draw_mix64((uint64_t)(uint32_t)u)) + (uint64_t)(uint32_t)d);
+    return (int32_t)(((z >> 32) * (uint64_t)(uint32_t)n_items) >> 32);
+}
+
+// model::sampleAUC (model.cpp:100-143) with the reference's sampling: n_draws candidate draws PER USER, a draw that
+// hits a clicked or held-out item is skipped and not replaced, every remaining draw is compared under the validation
+// and under the test context.  One wavefront per user, four draws per step (16 lanes each), scores in fp64 with the
+// summation of correct_clicked_kernel.  Writes (count_val, count_test, max) of the user.
+template <class T>
+__global__ void __launch_bounds__(256) sample_count_kernel(DevModel m, EvalDev ev, int n_draws, uint64_t seed, int32_t* __restrict__ draws_out)
+{
+    const int lane = threadIdx.x & 63, l16 = lane & 15, gq = lane >> 4;
+    const int w = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (w >= m.n_eval) return;
+    const int u = m.eval_users[w];
+    const int val = m.val_item[u], test = m.test_item[u];
+    const int32_t* clk = m.clk_item + m.clk_off[u]; const int nc = (int)(m.clk_off[u + 1] - m.clk_off[u]);
+    const int64_t w0 = (int64_t)w * ev.nctx;
+    const double* qv = ev.Q + w0 * ev.KQ;                                  // validation context
+    const double* qt = ev.nctx == 2 ? qv + ev.KQ : qv;                     // test context (the same query when the model has one)
+    const double thr_v = ev.thr[w0], thr_t = ev.nctx == 2 ? ev.thr[w0 + 1] : ev.thr2[w0];
+    const T* seg0 = ev.seg0 >= 0 ? (const T*)m.tab[ev.seg0] : nullptr;
+    const T* seg1 = ev.seg1 >= 0 ? (const T*)m.tab[ev.seg1] : nullptr;
+    const int K1 = ev.K1, K2 = ev.K2;
+    const bool l1 = m.model == REC_TRANSREC_L1, two = ev.nctx == 2;
+    int cv = 0, ct = 0, mx = 0;
+    for (int base = 0; base < n_draws; base += 4) {
+        const int d = base + gq;
+        const bool live = d < n_draws;
+        const int j = user_draw(seed, u, live ? d : 0, m.I);
+        if (draws_out && live && l16 == 0) draws_out[(int64_t)u * n_draws + d] = j;
+        const bool cand = live && j != test && j != val && !sorted_contains(clk, nc, j);
+        if (!__ballot(cand)) continue;
+        const int64_t ec = j;
+        double sv = 0, st = 0;
+        if (l1) {
+            for (int k = l16; k < K1; k += 16) { const double t = (double)seg0[ec * K1 + k]; sv += fabs(qv[k] - t); if (two) st += fabs(qt[k] - t); }
+            const double b = ev.bconst[ec];
+            sv = -(b + group_sum<16>(sv)); st = two ? -(b + group_sum<16>(st)) : sv;
+        } else {
+            for (int k = l16; k < K1; k += 16) { const double t = (double)seg0[ec * K1 + k]; sv += qv[k] * t; if (two) st += qt[k] * t; }
+            for (int k = l16; k < K2; k += 16) { const double t = (double)seg1[ec * K2 + k]; sv += qv[K1 + k] * t; if (two) st += qt[K1 + k] * t; }
+            const double b = ev.bconst[ec];
+            sv = group_sum<16>(sv) + b; st = two ? group_sum<16>(st) + b : sv;
+        }
+        mx += cand ? 1 : 0;
+        cv += (cand && thr_v > sv) ? 1 : 0;
+        ct += (cand && thr_t > st) ? 1 : 0;
+    }
+    // every lane of a group holds the group's counts: add the four groups
+    cv += __shfl_xor(cv, 16, 64); cv += __shfl_xor(cv, 32, 64);
+    ct += __shfl_xor(ct, 16, 64); ct += __shfl_xor(ct, 32, 64);
+    mx += __shfl_xor(mx, 16, 64); mx += __shfl_xor(mx, 32, 64);
+    if (lane == 0) { ev.counts[3 * (int64_t)u] = cv; ev.counts[3 * (int64_t)u + 1] = ct; ev.counts[3 * (int64_t)u + 2] = mx; }
+}
+
 template <class T>
 __global__ void gather_rows_kernel(const T* __restrict__ src, const int32_t* __restrict__ ids, int64_t n, int K, T* __restrict__ dst)
 {
@@ -909,7 +976,8 @@ static int launch_screen(const EvalDev& ev, const float* s0, const float* s1, in
 
 template <class T>
 static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host, hipStream_t st, double* score_ms,
-                     int64_t* score_launches, bool profile, const int32_t* subset_host, int n_subset)
+                     int64_t* score_launches, bool profile, const int32_t* subset_host, int n_subset, int user_draws, uint64_t draw_seed,
+                     int32_t* draws_host)
 {
     EvalDev ev = {};
     const int U = m.U, I = m.I;
@@ -973,6 +1041,30 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
     hipLaunchKernelGGL(build_queries_kernel<T>, dim3(blocks_for_waves(ev.nq)), dim3(256), 0, st, m, ev);
     EV_TRY(hipGetLastError());
     ev.col_b = ev.bconst;
+    if (user_draws > 0) {
+        // per-user candidate draws: no sweep, one wavefront per user scores its own draws
+        int32_t* d_draws = nullptr;
+        if (draws_host) {
+            EV_TRY(alloc((void**)&d_draws, sizeof(int32_t) * (size_t)U * user_draws));
+            EV_TRY(hipMemsetAsync(d_draws, 0xff, sizeof(int32_t) * (size_t)U * user_draws, st));
+        }
+        hipEvent_t s0 = nullptr, s1 = nullptr;
+        if (profile) { EV_TRY(hipEventCreate(&s0)); EV_TRY(hipEventCreate(&s1)); EV_TRY(hipEventRecord(s0, st)); }
+        hipLaunchKernelGGL(sample_count_kernel<T>, dim3(blocks_for_waves(m.n_eval)), dim3(256), 0, st, m, ev, user_draws, draw_seed, d_draws);
+        EV_TRY(hipGetLastError());
+        if (profile) EV_TRY(hipEventRecord(s1, st));
+        EV_TRY(hipMemcpyAsync(counts_host, ev.counts, sizeof(int32_t) * (size_t)U * 3, hipMemcpyDeviceToHost, st));
+        if (xpos_host) EV_TRY(hipMemcpyAsync(xpos_host, ev.xpos, sizeof(double) * (size_t)U * 2, hipMemcpyDeviceToHost, st));
+        if (draws_host) EV_TRY(hipMemcpyAsync(draws_host, d_draws, sizeof(int32_t) * (size_t)U * user_draws, hipMemcpyDeviceToHost, st));
+        EV_TRY(hipStreamSynchronize(st));
+        if (profile) {
+            float ms = 0; EV_TRY(hipEventElapsedTime(&ms, s0, s1));
+            *score_ms += ms; *score_launches += 1;
+            (void)hipEventDestroy(s0); (void)hipEventDestroy(s1);
+        }
+        release();
+        return 0;
+    }
     const T* seg0_cols = ev.seg0 >= 0 ? (const T*)m.tab[ev.seg0] : nullptr;
     const T* seg1_cols = ev.seg1 >= 0 ? (const T*)m.tab[ev.seg1] : nullptr;
     if (n_subset > 0) {
@@ -1245,8 +1337,9 @@ int eval_topk(const DevModel& m, int precision, const int32_t* users_host, int n
 }
 
 int eval_run(const DevModel& m, int precision, int32_t* counts_host, double* xpos_host, hipStream_t st, double* score_ms,
-             int64_t* score_launches, bool profile, const int32_t* subset_host, int n_subset)
+             int64_t* score_launches, bool profile, const int32_t* subset_host, int n_subset, int user_draws, uint64_t draw_seed,
+             int32_t* draws_host)
 {
-    return precision == REC_F64 ? eval_impl<double>(m, counts_host, xpos_host, st, score_ms, score_launches, profile, subset_host, n_subset)
-                                : eval_impl<float>(m, counts_host, xpos_host, st, score_ms, score_launches, profile, subset_host, n_subset);
+    return precision == REC_F64 ? eval_impl<double>(m, counts_host, xpos_host, st, score_ms, score_launches, profile, subset_host, n_subset, user_draws, draw_seed, draws_host)
+                                : eval_impl<float>(m, counts_host, xpos_host, st, score_ms, score_launches, profile, subset_host, n_subset, user_draws, draw_seed, draws_host);
 }

@@ -116,22 +116,45 @@ void model::AUC(double* AUC_val, double* AUC_test, double* HIT_val, double* HIT_
 
 // src/model.cpp:100-167 estimates the validation AUC from 2000 candidate draws per user because the exact value costs
 // the reference minutes.  Here the exact full-catalog value costs less than an epoch, so it is what train() compares
-// (no sampling noise in the early-stopping decision).  RECSYS_SAMPLED_VALIDATION=1 selects the estimate instead: one
-// draw of 2000 items shared by all users, fresh every call, scored by the kernels of AUC().
+// (no sampling noise in the early-stopping decision).  RECSYS_SAMPLED_VALIDATION=1 selects the reference's estimate
+// instead (2000 draws per user, fresh every call); =2 the cheaper variant with one draw of 2000 items shared by all users.
 void model::sampleAUC(double* AUC_val, double* AUC_test, double* var)
 {
     rec_metrics m;
     const char* sampled = getenv("RECSYS_SAMPLED_VALIDATION");
-    if (sampled && atoi(sampled) != 0) check(rec_eval_sampled(eng, 50, 2000, validation_calls++, &m, 0, 0));
+    const int mode = sampled ? atoi(sampled) : 0;
+    if (mode == 1) check(rec_eval_sampled_per_user(eng, 50, 2000, validation_calls++, &m, 0, 0));
+    else if (mode == 2) check(rec_eval_sampled(eng, 50, 2000, validation_calls++, &m, 0, 0));
     else check(rec_eval(eng, 50, &m, 0, 0));
     *AUC_val = m.auc_val; *AUC_test = m.auc_test; *var = m.var_test;
 }
 
 void model::MultipleMetrics(int topN, bool sample, double& valid)
 {
-    (void)sample;  // src/model.cpp:260 subsamples users above 50000; every user is evaluated here
     rec_metrics m;
-    check(rec_eval(eng, topN, &m, 0, 0));
+    if (sample && nUsers > 50000) {
+        // src/model.cpp:260: above 50000 users each valid user is kept with probability ~50000 / nUsers (same rand() test);
+        // every user is scored on the device, the subsample is taken from the per-user counts
+        std::vector<int32_t> counts((size_t)nUsers * 3);
+        check(rec_eval(eng, topN, &m, counts.data(), 0));
+        double s[6] = {0, 0, 0, 0, 0, 0};
+        int num_user = 0;
+        for (int u = 0; u < nUsers; u++) {
+            const int cv = counts[3 * (size_t)u], ct = counts[3 * (size_t)u + 1], mx = counts[3 * (size_t)u + 2];
+            if (mx < 0) continue;
+            if (rand() % nUsers > 50000) continue;
+            int rank = mx - ct + 1;
+            s[0] += 1.0 * ct / mx; s[1] += 1.0 / rank; s[2] += (rank <= topN);
+            rank = mx - cv + 1;
+            s[3] += 1.0 * cv / mx; s[4] += 1.0 / rank; s[5] += (rank <= topN);
+            num_user++;
+        }
+        m.n_users = num_user;
+        m.auc_test = s[0] / num_user; m.mrr_test = s[1] / num_user; m.hit_test = s[2] / num_user;
+        m.auc_val = s[3] / num_user; m.mrr_val = s[4] / num_user; m.hit_val = s[5] / num_user;
+    } else {
+        check(rec_eval(eng, topN, &m, 0, 0));
+    }
     printf("\n\n#Users = %d, VALID: AUC = %f, MRR = %f, HR@%d = %f\n", (int)m.n_users, m.auc_val, m.mrr_val, topN, m.hit_val);
     printf("#Users = %d, TEST:  AUC = %f, MRR = %f, HR@%d = %f\n", (int)m.n_users, m.auc_test, m.mrr_test, topN, m.hit_test);
     valid = m.hit_val;

@@ -33,8 +33,9 @@ def workdir(tmp_path_factory):
     return w
 
 
-def run(workdir, *args, expect=0):
-    r = subprocess.run([TRAIN] + [str(a) for a in args], cwd=workdir, capture_output=True, text=True, timeout=300)
+def run(workdir, *args, expect=0, env=None):
+    r = subprocess.run([TRAIN] + [str(a) for a in args], cwd=workdir, capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, **env) if env else None)
     assert r.returncode == expect, r.stdout[-2000:] + r.stderr[-2000:]
     return r.stdout
 
@@ -121,3 +122,24 @@ def test_run_shorter_than_the_first_validation_keeps_the_trained_model(workdir):
     m = re.search(r"Test AUC = ([0-9.]+), Val AUC = ([0-9.]+)", out)
     assert abs(float(m.group(1)) - mm[1]) < 2e-4 and abs(float(m.group(2)) - mm[0]) < 2e-4
     assert float(m.group(1)) > 0.55
+
+
+@pytest.mark.gpu
+def test_sampled_validation_modes_of_train(workdir):
+    """train() validates on the exact full-catalog AUC by default; RECSYS_SAMPLED_VALIDATION=1 brings back the reference's
+    estimate (model::sampleAUC, model.cpp:100-167: 2000 draws per user), =2 one draw shared by all users.  The epochs are
+    the same in all three runs (the device sampler does not share a random stream with the validation), so the printed
+    validation values are three estimates of the same numbers."""
+    args = (f"01-Data/{ML5}.txt", 0, 0, 1, 1, 10, 0.01, 0.01, 0, 0, 100, "03-Models/v", "BPRMF")
+
+    def valid_lines(out):
+        return [(float(a), float(b)) for a, b in re.findall(r"^\[Valid AUC = ([0-9.]+)\], Test AUC = ([0-9.]+)", out, flags=re.M)]
+
+    exact = valid_lines(run(workdir, *args))
+    per_user = valid_lines(run(workdir, *args, env={"RECSYS_SAMPLED_VALIDATION": "1"}))
+    shared = valid_lines(run(workdir, *args, env={"RECSYS_SAMPLED_VALIDATION": "2"}))
+    assert len(exact) == len(per_user) == len(shared) == 2
+    for x, p, s_ in zip(exact, per_user, shared):
+        # the reference's estimator has a standard deviation of about 1.2e-4 on this corpus (tests/golden/ml5_sampleauc.json)
+        assert p != x and abs(p[0] - x[0]) < 7e-4 and abs(p[1] - x[1]) < 7e-4, (x, p)
+        assert abs(s_[0] - x[0]) < 0.03 and abs(s_[1] - x[1]) < 0.03, (x, s_)

@@ -188,6 +188,80 @@ def test_sampled_eval_counts_match_oracle_on_the_same_draws(model):
     e.close()
 
 
+@pytest.mark.parametrize("prec", [F64, F32])
+@pytest.mark.parametrize("model", EVAL_MODELS)
+def test_per_user_sampled_eval_counts_match_oracle_on_the_same_draws(model, prec):
+    """rec_eval_sampled_per_user (model::sampleAUC with the reference's sampling, model.cpp:119-140): every user has
+    draws of its own; for the draws the engine reports, (count_val, count_test, max) must be what the reference's loop
+    computes on them - a draw that hits a clicked or held-out item is skipped and not replaced."""
+    g, model, co, ci, labels = fixture_case(model, "toy")
+    e = make_engine(g, model, co, ci, labels, prec)
+    W = g["W1"] if model != "MP" else None
+    if W is not None:
+        e.upload(W)
+        W = e.download()     # f32 tables: the oracle scores the rounded values
+    o = make_oracle(g, model, co, ci, labels)
+    n_draws = 90
+    m, counts, draws = e.eval_sampled_per_user(n_sampled=n_draws, seed=11, want_draws=True)
+    I = int(g["n_items"])
+    full = np.asarray(g["counts"])
+    n_ok, rows_seen = 0, set()
+    for u in range(len(full)):
+        if full[u, 2] < 0:
+            assert (counts[u] == -1).all() and (draws[u] == -1).all()
+            continue
+        assert draws[u].min() >= 0 and draws[u].max() < I
+        rows_seen.add(tuple(draws[u].tolist()))
+        rows = [o.score_row(W, u, 0), o.score_row(W, u, 1)]
+        pos = [int(o.val_item[u]), int(o.test_item[u])]
+        cand = [j for j in draws[u].tolist() if np.isfinite(rows[0][j]) and j not in pos]
+        if not cand:
+            assert (counts[u] == -1).all()
+            continue
+        want = [sum(1 for j in cand if rows[c][pos[c]] > rows[c][j]) for c in (0, 1)]
+        assert counts[u].tolist() == [want[0], want[1], len(cand)], (model, u)
+        n_ok += 1
+    assert n_ok > 10 and int(m.n_users) == n_ok
+    assert len(rows_seen) == n_ok            # no two users share their draws
+    # the same seed gives the same draws, another seed others
+    again = e.eval_sampled_per_user(n_draws, seed=11, want_draws=True)
+    other = e.eval_sampled_per_user(n_draws, seed=12, want_draws=True)
+    assert np.array_equal(again[2], draws) and np.array_equal(again[1], counts) and not np.array_equal(other[2], draws)
+    # draws are uniform over the catalog: every item is drawn, none far more often than the others
+    hist = np.bincount(draws[draws >= 0], minlength=I)
+    assert hist.min() > 0 and hist.max() < 2.5 * hist.mean()
+    e.close()
+
+
+@pytest.mark.parametrize("tag", ["BPRMF", "TransRec", "Fossil", "REBUS_mc2_L3"])
+def test_per_user_sampled_validation_has_the_spread_of_the_reference(tag):
+    """The reference's own sampleAUC on its saved ML-5 models, 24 consecutive calls (tests/golden/ml5_sampleauc.json,
+    oracle/make_sampleauc.py): its item-sampling error averages out over the 6039 users (standard deviation about 1e-4).
+    The per-user estimator here must show the same spread around the same exact value; one draw shared by all users
+    (rec_eval_sampled) does not average out and is an order of magnitude noisier."""
+    import json
+    import os
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ml5_sampleauc.json")))[tag]
+    g, model, co, ci, labels = fixture_case(tag, "ml5")
+    e = make_engine(g, model, co, ci, labels, F64)
+    e.upload(g["W_micro"].astype(np.float64) / 1e6)
+    exact = e.eval()[0]
+    assert abs(exact.auc_val - ref["exact_auc_val"]) < 1e-9 and abs(exact.auc_test - ref["exact_auc_test"]) < 1e-9
+    per_user = np.array([[m.auc_val, m.auc_test, m.var_test] for m in (e.eval_sampled_per_user(2000, seed=s)[0] for s in range(24))])
+    shared = np.array([[m.auc_val, m.auc_test] for m in (e.eval_sampled(2000, seed=s)[0] for s in range(24))])
+    for c, key, ex in ((0, "auc_val", exact.auc_val), (1, "auc_test", exact.auc_test)):
+        r = np.array(ref[key])
+        sd_ref, sd = r.std(ddof=1), per_user[:, c].std(ddof=1)
+        assert 0.5 * sd_ref < sd < 2.0 * sd_ref, (tag, key, sd, sd_ref)
+        # both are unbiased for the exact value: means of 24 calls within 4 standard errors of it
+        assert abs(per_user[:, c].mean() - ex) < 4 * sd_ref / np.sqrt(24) + 1e-5, (tag, key, per_user[:, c].mean(), ex)
+        assert abs(r.mean() - ex) < 4 * sd_ref / np.sqrt(24) + 1e-5
+        assert shared[:, c].std(ddof=1) > 3 * sd, (tag, key, shared[:, c].std(ddof=1), sd)
+    # "Test var" of the printed validation line: the variance over users of the per-user estimates
+    assert abs(per_user[:, 2].mean() - np.mean(ref["var_test"])) < 2e-4
+    e.close()
+
+
 @pytest.mark.parametrize("tag", ["BPRMF", "TransRec", "REBUS_mc2_L3"])
 def test_eval_f32_storage_matches_oracle_on_same_values(tag):
     """f32 tables are scored in f64 after an exact widening, so the oracle fed the rounded values must agree."""
