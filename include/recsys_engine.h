@@ -248,6 +248,9 @@ int rec_table_info(const rec_engine* e, int t, void** dev_ptr, int64_t* rows, in
  *                   decided in fp64, so the counts are those of the fp64 sweep.  0: fp64 sweep.  (process-wide)
  *   "eval_screen_cap"  columns per query the screen may leave to fp64 (default 0 = max(64, n_items / 2048)); a query that
  *                   needs more makes the whole sweep run again in fp64
+ *   "eval_ranges"   ranges the f32 screen cuts the catalog into, each swept by its own blocks (0, the default: one range
+ *                   unless the query blocks alone would not fill the chip evenly - few users per engine; then up to 16).  The
+ *                   counts do not depend on it.  (process-wide)
  *   "profile"       time every update / scoring / sampler launch with HIP events */
 int rec_set_option(rec_engine* e, const char* name, int64_t value);
 

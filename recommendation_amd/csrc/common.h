@@ -144,6 +144,7 @@ int launch_event_sampler(const DevModel& m, int4* tuples, int64_t cap, int64_t n
 // draw_seed, the user and the draw index; draws_host, optional, [U][user_draws] receives them, -1 for users not evaluated).
 // f32 screen of the full-catalog sweep (f32 tables): on (1) / off (0) / unchanged (-1); columns a query may leave to fp64 (cap > 0)
 void eval_configure_screen(int on, int cap);
+void eval_configure_ranges(int ranges);   // ranges of the catalog per query block in the screen (0 = chosen from the number of query blocks)
 void eval_screen_stats(int* mode, int64_t* open);   // of the last full-catalog sweep: 0 fp64 / 1 screen / 2 screen overflowed; undecided columns ("profile" on)
 int eval_run(const DevModel& m, int precision, int32_t* counts_host, double* xpos_host, hipStream_t st,
              double* score_ms, int64_t* score_launches, bool profile, const int32_t* subset_host, int n_subset,

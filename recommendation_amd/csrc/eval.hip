@@ -43,6 +43,9 @@ struct EvalDev {
     int amb_cap;
     int32_t* amb_overflow;
     int heldout_counted;       // 1: the sweep counted the test / validation items like any column (the screen does): taken out afterwards
+    // the screen's catalog split: blockIdx.y sweeps items [y * range_items, (y + 1) * range_items); with more than one range
+    // the counts and the undecided lists of a query are shared by its blocks (integer atomics on zeroed arrays)
+    int ranges, range_items;
 };
 
 #define E REC_MAX_EPL
@@ -549,9 +552,13 @@ __global__ void __launch_bounds__(256, DENSE && KQ <= 64 ? 3 : 2) score_screen_k
         }
     };
 
+    // this block's part of the catalog (a whole number of tiles; the last range ends with the catalog)
+    const int i_begin = (int)blockIdx.y * ev.range_items;
+    const int i_end = (int)min((int64_t)I, (int64_t)i_begin + ev.range_items);
+    const bool shared_lists = ev.ranges > 1;
     float4_t pre[PER4]; float preb;
-    fetch(0, pre, preb);
-    for (int item0 = 0; item0 < I; item0 += NI) {
+    fetch(i_begin, pre, preb);
+    for (int item0 = i_begin; item0 < i_end; item0 += NI) {
         __syncthreads();
 #pragma unroll
         for (int p = 0; p < PER4; p++) {
@@ -560,7 +567,7 @@ __global__ void __launch_bounds__(256, DENSE && KQ <= 64 ? 3 : 2) score_screen_k
         }
         if (tid < NI) tile_b[tid] = preb;
         __syncthreads();
-        if (item0 + NI < I) fetch(item0 + NI, pre, preb);
+        if (item0 + NI < i_end) fetch(item0 + NI, pre, preb);
 #pragma unroll 1
         for (int sub = 0; sub < NI / 16; sub++) {
             const int jj = sub * 16 + col;
@@ -612,16 +619,23 @@ __global__ void __launch_bounds__(256, DENSE && KQ <= 64 ? 3 : 2) score_screen_k
                 open &= open - 1;
                 const int qi = qw + (e >> 2) * 16 + 4 * quad + (e & 3);
                 const int which = (int)((open1 >> e) & 1u) | ((int)((open2 >> e) & 1u) << 1);
-                const int at = atomicAdd(&q_amb[qi], 1);
+                int at;
+                if (shared_lists) {
+                    at = atomicAdd(&ev.amb_cnt[qblock + qi], 1);
+                    if (at >= ev.amb_cap) *ev.amb_overflow = 1;
+                } else {
+                    at = atomicAdd(&q_amb[qi], 1);
+                }
                 if (at < ev.amb_cap) ev.amb[(qblock + qi) * (int64_t)ev.amb_cap + at] = j | (which << 28);
             }
         }
     }
     __syncthreads();
-    for (int i = tid; i < QB; i += 256) {
-        ev.amb_cnt[qblock + i] = q_amb[i];
-        if (q_amb[i] > ev.amb_cap) *ev.amb_overflow = 1;
-    }
+    if (!shared_lists)
+        for (int i = tid; i < QB; i += 256) {
+            ev.amb_cnt[qblock + i] = q_amb[i];
+            if (q_amb[i] > ev.amb_cap) *ev.amb_overflow = 1;
+        }
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
@@ -631,30 +645,38 @@ __global__ void __launch_bounds__(256, DENSE && KQ <= 64 ? 3 : 2) score_screen_k
             for (int o = 8; o > 0; o >>= 1) { c += __shfl_xor(c, o, 64); if (TWO) c2 += __shfl_xor(c2, o, 64); }
             if (col == 0) {
                 const int64_t qi = qblock + qw + mt * 16 + 4 * quad + r;
-                ev.cnt[qi] = c;
-                if (TWO) ev.cnt2[qi] = c2;
+                if (shared_lists) {
+                    atomicAdd(&ev.cnt[qi], c);
+                    if (TWO) atomicAdd(&ev.cnt2[qi], c2);
+                } else {
+                    ev.cnt[qi] = c;
+                    if (TWO) ev.cnt2[qi] = c2;
+                }
             }
         }
 }
 
-// max_j ||T_j||_2 and max_j |b_j| (as the bit patterns of non-negative floats, which order like unsigned integers); one
-// wavefront per item
+// max_j ||T_j||_2 and max_j |b_j| (as the bit patterns of non-negative floats, which order like unsigned integers).  A
+// wavefront walks items wave, wave + waves, ... and publishes its two maxima once (one atomic per item on the same two
+// words serializes: 4.5 ms for 200k items)
 __global__ void __launch_bounds__(256) screen_item_bounds_kernel(EvalDev ev, const float* __restrict__ seg0, const float* __restrict__ seg1, int I,
                                                                  unsigned* __restrict__ out)
 {
     const int lane = threadIdx.x & 63;
-    const int j = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    if (j >= I) return;
-    double s = 0;
-    for (int k = lane; k < ev.K1; k += 64) { const double t = (double)seg0[(int64_t)j * ev.K1 + k]; s += t * t; }
-    for (int k = lane; k < ev.K2; k += 64) { const double t = (double)seg1[(int64_t)j * ev.K2 + k]; s += t * t; }
-    s = group_sum<64>(s);
-    if (lane == 0) {
+    const int wave = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int waves = (int)(((int64_t)gridDim.x * blockDim.x) >> 6);
+    unsigned nmax = 0, bmax = 0;
+    for (int j = wave; j < I; j += waves) {
+        double s = 0;
+        for (int k = lane; k < ev.K1; k += 64) { const double t = (double)seg0[(int64_t)j * ev.K1 + k]; s += t * t; }
+        for (int k = lane; k < ev.K2; k += 64) { const double t = (double)seg1[(int64_t)j * ev.K2 + k]; s += t * t; }
+        s = group_sum<64>(s);
         const float n = __double2float_ru(sqrt(s) * 1.000001), b = __double2float_ru(fabs(ev.bconst[j]) * 1.000001);
         // NaN / infinity in the tables: the margins become NaN / infinite and every column goes to the fp64 path or is dropped as there
-        atomicMax(out, __float_as_uint(n == n ? n : INFINITY));
-        atomicMax(out + 1, __float_as_uint(b == b ? b : INFINITY));
+        nmax = max(nmax, __float_as_uint(n == n ? n : INFINITY));
+        bmax = max(bmax, __float_as_uint(b == b ? b : INFINITY));
     }
+    if (lane == 0) { atomicMax(out, nmax); atomicMax(out + 1, bmax); }
 }
 
 // the margin of every query; one wavefront per query
@@ -948,6 +970,8 @@ static int launch_score(const EvalDev& ev, const T* s0, const T* s1, int n_cols,
 static unsigned blocks_for_waves(int64_t waves) { return (unsigned)((waves * 64 + 255) / 256); }
 
 static int g_screen_on = 1, g_screen_cap = 0;   // cap 0: by the size of the catalog (see eval_impl)
+static int g_screen_ranges = 0;         // ranges the screen cuts the catalog into (0: by the number of query blocks, see eval_impl)
+void eval_configure_ranges(int ranges) { g_screen_ranges = ranges; }
 static int g_screen_mode = 0;           // how the last full-catalog sweep ran: 0 fp64, 1 f32 screen, 2 screen overflowed and fp64 took over
 static int64_t g_screen_open = 0;       // columns the last screen left to fp64, over all queries
 void eval_configure_screen(int on, int cap) { if (on >= 0) g_screen_on = on; if (cap >= 0) g_screen_cap = cap; }
@@ -961,8 +985,8 @@ static int launch_screen(const EvalDev& ev, const float* s0, const float* s1, in
 #define SCREEN_CASE(KQv)                                                                                        \
     case KQv: {                                                                                                 \
         const unsigned blocks = (unsigned)(ev.nq_pad / (4 * ScreenShape<KQv>::MT * 16));                        \
-        if (ev.K1 + ev.K2 == KQv && ev.K1 % 4 == 0 && ev.K2 % 4 == 0) hipLaunchKernelGGL((score_screen_kernel<KQv, TWO, true>), dim3(blocks), dim3(256), 0, st, ev, s0, s1, qtest, qval, n_cols); \
-        else hipLaunchKernelGGL((score_screen_kernel<KQv, TWO, false>), dim3(blocks), dim3(256), 0, st, ev, s0, s1, qtest, qval, n_cols); \
+        if (ev.K1 + ev.K2 == KQv && ev.K1 % 4 == 0 && ev.K2 % 4 == 0) hipLaunchKernelGGL((score_screen_kernel<KQv, TWO, true>), dim3(blocks, ev.ranges), dim3(256), 0, st, ev, s0, s1, qtest, qval, n_cols); \
+        else hipLaunchKernelGGL((score_screen_kernel<KQv, TWO, false>), dim3(blocks, ev.ranges), dim3(256), 0, st, ev, s0, s1, qtest, qval, n_cols); \
         break;                                                                                                  \
     }
     switch (ev.KQ) {
@@ -1108,6 +1132,25 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
         EV_TRY(alloc((void**)&bounds, sizeof(unsigned) * 2));
         EV_TRY(hipMemsetAsync(ev.amb_overflow, 0, sizeof(int32_t), st));
         EV_TRY(hipMemsetAsync(bounds, 0, sizeof(unsigned) * 2, st));
+        // A block keeps its queries for a sweep of the catalog, so a launch has nq_pad / qblock blocks: with few queries (a
+        // rank's share of the users, a small corpus) they do not fill the chip evenly - 977 blocks on 768 resident places run
+        // as one full round and a quarter-full one.  The catalog is then cut into ranges (grid.y) until there are about 8
+        // rounds of blocks; a query's blocks add their counts and share its list through integer atomics.
+        {
+            int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            const int64_t resident = (int64_t)cus * 3, blocks = ev.nq_pad / qblock;
+            const int tile = 128;                                       // a multiple of every tile shape's item count
+            int ranges = g_screen_ranges > 0 ? std::min(g_screen_ranges, (I + tile - 1) / tile)
+                                             : (int)std::min<int64_t>(std::min<int64_t>(16, (8 * resident + blocks - 1) / blocks), (I + 4095) / 4096);   // at least 4096 items per range
+            ranges = std::max(1, ranges);
+            ev.range_items = (int)((((int64_t)I + ranges - 1) / ranges + tile - 1) / tile * tile);
+            ev.ranges = (I + ev.range_items - 1) / ev.range_items;
+            if (ev.ranges > 1) {
+                EV_TRY(hipMemsetAsync(ev.cnt, 0, sizeof(int32_t) * ev.nq_pad, st));
+                EV_TRY(hipMemsetAsync(ev.cnt2, 0, sizeof(int32_t) * ev.nq_pad, st));
+                EV_TRY(hipMemsetAsync(ev.amb_cnt, 0, sizeof(int32_t) * ev.nq_pad, st));
+            }
+        }
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (profile) { EV_TRY(hipEventCreate(&e0)); EV_TRY(hipEventCreate(&e1)); EV_TRY(hipEventRecord(e0, st)); }
@@ -1115,7 +1158,7 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
     if (l1) {
         rc = launch_score_l1<T, false>(ev, seg0_cols, qtest, qval, NC, m.K, st);
     } else if (screen) {
-        hipLaunchKernelGGL(screen_item_bounds_kernel, dim3(blocks_for_waves(I)), dim3(256), 0, st, ev, (const float*)seg0_cols, (const float*)seg1_cols, I, bounds);
+        hipLaunchKernelGGL(screen_item_bounds_kernel, dim3(std::min(1024u, blocks_for_waves(I))), dim3(256), 0, st, ev, (const float*)seg0_cols, (const float*)seg1_cols, I, bounds);
         ev.heldout_counted = 1;
         hipLaunchKernelGGL(screen_margins_kernel, dim3(blocks_for_waves(ev.nq_pad)), dim3(256), 0, st, ev, (const unsigned*)bounds);
         rc = ev.nctx == 1 ? launch_screen<true>(ev, (const float*)seg0_cols, (const float*)seg1_cols, NC, qtest, qval, st)

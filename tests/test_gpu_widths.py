@@ -124,7 +124,10 @@ def test_f32_screen_gives_the_counts_of_the_fp64_sweep(model, K):
         W = np.round(W * 8) / 8
         e.upload(W)
     got = {}
-    for name, opts in (("fp64", {"eval_screen": 0}), ("screen", {"eval_screen": 1, "eval_screen_cap": 1024}), ("overflow", {"eval_screen_cap": 1})):
+    # ("eval_ranges": the catalog cut into that many ranges, each swept by blocks of its own that share a query's counts and
+    # list; 0 = chosen from the number of query blocks - two ranges here)
+    for name, opts in (("fp64", {"eval_screen": 0}), ("screen", {"eval_screen": 1, "eval_screen_cap": 1024}),
+                       ("one_range", {"eval_ranges": 1}), ("seven_ranges", {"eval_ranges": 7}), ("overflow", {"eval_screen_cap": 1, "eval_ranges": 0})):
         for k, v in opts.items():
             e.set_option(k, v)
         _, counts, _ = e.eval()
@@ -136,6 +139,9 @@ def test_f32_screen_gives_the_counts_of_the_fp64_sweep(model, K):
     assert got["overflow"][1] == 2 if model in ("BPRMF", "FPMC") else got["overflow"][1] in (1, 2), [g[1:] for g in got.values()]
     assert got["screen"][2] > 0                       # the grid puts columns on the thresholds: some must have gone to fp64
     assert np.array_equal(got["screen"][0], got["fp64"][0])
+    for name in ("one_range", "seven_ranges"):
+        assert got[name][1] == 1 and got[name][2] == got["screen"][2], (name, got[name][1:], got["screen"][1:])
+        assert np.array_equal(got[name][0], got["fp64"][0]), name
     assert np.array_equal(got["overflow"][0], got["fp64"][0])
     o = orc.Oracle(model, U, I, K, seq_off, seq_item, test, val, path_off=po, path_item=pi, **{k: v for k, v in kw.items() if k != "K"})
     _, ref = o.eval(W)
