@@ -240,6 +240,9 @@ int rec_table_info(const rec_engine* e, int t, void** dev_ptr, int64_t* rows, in
  *                   training sequence has >= 16 clicks, else 1: with very short histories the tuples of a group mostly coincide
  *                   and the summed step can diverge);
  *                   (rec_sgd_replay in Hogwild mode uses it when its tuples come grouped the same way)
+ *   "pair_min_history"  a group of "user_batch" tuples shares one walk (all of them stepping from the parameters the group
+ *                   found) only when its user has at least this many training clicks (default 8); the tuples of a user
+ *                   with fewer are applied one after the other by the same wavefront, each seeing the one before it
  *   "stale_window"  tuples per update launch for small catalogs (0 = no limit)
  *   "global_window" tuples per update launch for models with a row every tuple touches
  *   "global_cap"    such a row moves by at most this many steps' worth of learning rate per launch

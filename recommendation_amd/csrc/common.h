@@ -34,6 +34,7 @@ struct DevModel {
     const int64_t* sset_off;            // ... and as sorted distinct sets
     const int32_t* sset_item;
     int* work_counter;                  // next unclaimed tuple group of the running history launch
+    int pair_min_hist;                  // history kernels: a group of tuples shares one walk only when its user has at least this many training clicks
     void* gacc;                         // accumulators for rows every tuple touches (TransRec r, Fossil WT, FossilSimple alpha)
     const int32_t* eval_users;          // users of this engine's shard that have a test item
     int n_eval;

@@ -379,9 +379,12 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     // run-to-run noise (lr 0.01: 0.8125 vs 0.8124; lr 0.05, REBUS: 0.7794 vs 0.7789).  Both tuples step from the same
     // parameters, which on users with a handful of clicks (where the two tuples mostly coincide) doubles the step: on
     // the bundled ML-5 corpus (<= 3 training clicks per user) REBUS at lr 0.05 then diverges in about 1 run of 10.  So
-    // pairs are only the default where histories are long; "user_batch" sets it either way.
+    // pairs are only the default where histories are long; "user_batch" sets it either way.  Whatever the mean, a user
+    // with fewer than "pair_min_history" (8) training clicks never shares a walk: the kernel applies that user's tuples
+    // one after the other.
     const double mean_history = U > 0 ? (double)E / (double)U : 0.0;
     e->user_batch = (history_model(d->model) && e->steps_per_epoch >= (1 << 22) && mean_history >= 16.0) ? 2 : 1;
+    e->dm.pair_min_hist = 8;
     // Owner mode ("owner_neg": launches partitioned by the negative's slice of the catalog, the negatives' deltas summed in
     // LDS by the workgroup that owns the slice) removes half of the float atomics, which bound the update kernel, but it
     // is off by default: within a launch an item's steps in the negative's role come when its workgroup gets to them,
@@ -1089,6 +1092,7 @@ extern "C" int rec_set_option(rec_engine* e, const char* name, int64_t value)
         e->pos_share = (int)value;
     }
     else if (s == "share_negative") { if (value != 1 && value != 2 && value != 4) { rec_set_error("share_negative must be 1, 2 or 4"); return -1; } e->neg_share = (int)value; }
+    else if (s == "pair_min_history") { if (value < 0 || value > (1 << 20)) { rec_set_error("pair_min_history must be in 0..2^20"); return -1; } e->dm.pair_min_hist = (int)value; }
     else if (s == "user_batch") { if (value != 1 && value != 2 && value != 4 && value != 8) { rec_set_error("user_batch must be 1, 2, 4 or 8"); return -1; } e->user_batch = (int)value; }
     else if (s == "wide") { if (value != 0 && value != 1) { rec_set_error("wide must be 0 or 1"); return -1; } e->wide = (int)value; }
     else if (s == "owner_neg") { if (value != 0 && value != 1) { rec_set_error("owner_neg must be 0 or 1"); return -1; } e->owner = (int)value; }

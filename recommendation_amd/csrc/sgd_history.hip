@@ -123,16 +123,27 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
         const int64_t first = (int64_t)uni(next) * CLAIM;
         if (first >= ngroups) break;
         if (lane == 0) next = atomicAdd(m.work_counter, 1);
-      for (int64_t gi = first; gi < first + CLAIM && gi < ngroups; gi++) {
-        const int64_t base = gi * G;
-        const int ng = (int)(n - base < G ? n - base : G);
-        int4 tg[G];
-#pragma unroll
-        for (int g = 0; g < G; g++) tg[g] = tuples[base + (g < ng ? g : 0)];
-        const int u = uni(tg[0].x);
+      const int64_t t_end = (first + CLAIM) * G < n ? (first + CLAIM) * G : n;
+      int step = G;
+      for (int64_t base = first * G; base < t_end; base += step) {
+        const int u = uni(tuples[base].x);
         const int64_t so = uni(m.seq_off[u]);
         const int32_t* seq = m.seq_item + so;
         const int nu = uni((int)(m.seq_off[u + 1] - so));
+        // The tuples of a group all step from the parameters the group found.  On a user with a handful of clicks they
+        // mostly name the same few rows, so the summed step is close to a single step of G times the learning rate (REBUS
+        // on a corpus of 3-click users diverged that way).  Such a user's tuples are applied one after the other
+        // instead - its history is short, so the shared walk saves little - each waiting for the scatters of the one
+        // before it and dropping what the vector cache holds of the rows.
+        const bool alone = G > 1 && nu < m.pair_min_hist;
+        const int in_group = (int)(base % G);                        // non-zero only inside a group that is applied tuple by tuple
+        const int left = (int)(n - base < G - in_group ? n - base : G - in_group);
+        const int ng = alone ? 1 : left;
+        step = ng;
+        if (alone && in_group != 0) { __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+        int4 tg[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) tg[g] = tuples[base + (g < ng ? g : 0)];
 
         if constexpr (MODEL == REC_FOSSIL || MODEL == REC_FOSSIL_SIMPLE) {
             constexpr bool SIMPLE = MODEL == REC_FOSSIL_SIMPLE;

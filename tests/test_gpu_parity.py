@@ -488,6 +488,7 @@ def test_user_batched_history_kernel_sums_the_single_tuple_steps(model, G):
     e.set_option("update_policy", 0)
     T1 = e.sample_tuples(4096, seed=5, epoch=2)
     e.set_option("user_batch", G)
+    e.set_option("pair_min_history", 0)     # the toy users are short: shared walks for them too (see the test below)
     T = e.sample_tuples(4096, seed=5, epoch=2)
     assert (T[:, 0].reshape(-1, G) == T[::G, 0][:, None]).all()          # groups share their user
     R = T.reshape(-1, G, 4)
@@ -533,6 +534,45 @@ def test_user_batched_history_kernel_sums_the_single_tuple_steps(model, G):
             e.sgd_replay(lr, mixed, HOGWILD)
             assert rel_err(e.download(), ref, floor=1e-1) < 1e-9
             break
+    e.close()
+
+
+@pytest.mark.parametrize("G", [2, 4])
+@pytest.mark.parametrize("model", ["FossilSimple", "Fossil", "REBUS"])
+def test_groups_of_a_short_user_are_applied_one_after_the_other(model, G):
+    """A user with fewer than "pair_min_history" (default 8) training clicks never shares a walk: stepping G nearly
+    identical tuples from the same parameters multiplies the step.  The kernel applies such a group tuple by tuple, each
+    seeing the one before it: the group equals G launches of one tuple each (REBUS: to rounding; Fossil / FossilSimple fold
+    the gradient of their global weights once per launch, which moves the second tuple by O(lr^2))."""
+    g, model, co, ci, labels = fixture_case(model, "toy")
+    o = make_oracle(g, model, co, ci, labels)
+    seq_off, _, _, _ = orc.split(co, ci)
+    lr = float(g["lr"]); W0 = g["W0"]
+    e = make_engine(g, model, co, ci, labels, F64)
+    e.set_option("update_policy", 0)
+    e.set_option("user_batch", G)
+    T = e.sample_tuples(96 * G, seed=8, epoch=1)
+    worst_seq = worst_sum = 0.0
+    n = 0
+    for k in range(0, 96 * G, G):
+        grp = T[k:k + G]
+        if seq_off[grp[0, 0] + 1] - seq_off[grp[0, 0]] >= 8:
+            continue
+        n += 1
+        e.upload(W0)
+        e.sgd_replay(lr, grp, HOGWILD)
+        got = e.download()
+        e.upload(W0)
+        for t in grp:
+            e.sgd_replay(lr, t[None, :], HOGWILD)
+        one_by_one = e.download()
+        summed = W0 + sum(o.replay(W0, t[None, :], lr) - W0 for t in grp)
+        worst_seq = max(worst_seq, rel_err(got, one_by_one, floor=1e-1))
+        worst_sum = max(worst_sum, rel_err(got, summed, floor=1e-1))
+    assert n >= 20
+    # measured: REBUS identical; FossilSimple / Fossil 5e-4 / 3e-4 (G = 2), 2.8e-3 / 1.5e-3 (G = 4); against the summed step 0.05 .. 0.33
+    assert worst_seq < (1e-9 if model == "REBUS" else 1e-3 * G), (model, G, worst_seq)
+    assert worst_sum > 1e-2 and worst_sum > 10 * worst_seq, (model, G, worst_sum, worst_seq)    # ... and not the sum of steps taken from the same parameters
     e.close()
 
 
