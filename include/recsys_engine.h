@@ -195,6 +195,24 @@ int64_t rec_fsub_mine(int32_t n_users, int32_t n_items, const int64_t* seq_off, 
 int rec_num_tables(const rec_engine* e);
 int rec_table_info(const rec_engine* e, int t, void** dev_ptr, int64_t* rows, int64_t* cols, int* is_user_table);
 
+/* No counterpart in the reference (one process, one thread).  User-sharded training inside one process: `shards` are n
+ * engines of one model created with consecutive user ranges (rec_model_desc.user_begin / user_end), all on one device or
+ * one per device (1 <= n <= 16).  A round: rec_shards_begin_round keeps the common value of every table that is not
+ * indexed by user; each shard applies its share of the tuples (rec_sgd_epoch); rec_shards_combine sets every replica to
+ * base + sum over the shards of (table - base).  Shards on different devices are combined by one RCCL all-reduce (sum)
+ * per table over xGMI (librccl is loaded at the first such call), shards on one device by one kernel.  Both calls wait
+ * for the shards' streams.  rec_device_count: HIP devices visible to the process. */
+int rec_device_count(void);
+int rec_shards_begin_round(rec_engine* const* shards, int n);
+int rec_shards_combine(rec_engine* const* shards, int n);
+
+/* replaces: TransRec::normalization (TransRec.cpp:245-258) over every item row: rows longer than 1 are scaled back onto
+ * the unit ball (nothing to do for the other models).  The update launches do it themselves unless
+ * "project_after_launch" is 0 - which sharded training sets, because the projection is not additive: each shard's launches
+ * then only add gradient steps, and the combined table is projected once (rec_shards_combine does it; a caller that
+ * combines the tables itself, e.g. with RCCL through torch.distributed, calls this afterwards). */
+int rec_project_rows(rec_engine* e);
+
 /* Tuning knobs (value 0/1 unless noted):
  *   "owner_neg"     BPRMF / MC / FPMC / PRME / HRM / TransRec, default 0: 1 = a launch of at least "owner_min" tuples is
  *                   first partitioned by the slice of the catalog its negative items lie in, and workgroup s of the update
@@ -251,6 +269,8 @@ int rec_table_info(const rec_engine* e, int t, void** dev_ptr, int64_t* rows, in
  *                   decided in fp64, so the counts are those of the fp64 sweep.  0: fp64 sweep.  (process-wide)
  *   "eval_screen_cap"  columns per query the screen may leave to fp64 (default 0 = max(64, n_items / 2048)); a query that
  *                   needs more makes the whole sweep run again in fp64
+ *   "project_after_launch"  TransRec: 1 (default) = every update launch ends with the projection of all item rows onto the unit
+ *                   ball; 0 = the caller does it (rec_project_rows), see there
  *   "eval_ranges"   ranges the f32 screen cuts the catalog into, each swept by its own blocks (0, the default: one range
  *                   unless the query blocks alone would not fill the chip evenly - few users per engine; then up to 16).  The
  *                   counts do not depend on it.  (process-wide)

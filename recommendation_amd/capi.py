@@ -15,7 +15,7 @@ SEQUENTIAL, HOGWILD = 0, 1
 EXPORTS = ["rec_last_error", "rec_create", "rec_destroy", "rec_sync", "rec_nw", "rec_params_upload",
            "rec_params_download", "rec_params_read", "rec_params_init", "rec_snapshot_best", "rec_restore_best", "rec_sgd_replay", "rec_sgd_replay_static", "rec_partition_tuples", "rec_owner_slices",
            "rec_sgd_epoch", "rec_sample_tuples", "rec_sample_events", "rec_tuples_drawn", "rec_steps_per_epoch", "rec_eval", "rec_eval_sampled", "rec_eval_sampled_per_user", "rec_eval_topk", "rec_eval_sums",
-           "rec_rebus_build_paths", "rec_fsub_mine", "rec_num_tables", "rec_table_info", "rec_set_option", "rec_kernel_stats"]
+           "rec_device_count", "rec_shards_begin_round", "rec_shards_combine", "rec_project_rows", "rec_rebus_build_paths", "rec_fsub_mine", "rec_num_tables", "rec_table_info", "rec_set_option", "rec_kernel_stats"]
 
 
 class RecCorpus(C.Structure):
@@ -124,6 +124,7 @@ class Engine:
                             device, user_begin, user_end)
         _check(lib().rec_create(C.byref(corpus), C.byref(desc), C.byref(self.handle)))
         self.precision = precision
+        self.model = model
         self.user_begin, self.user_end = (0, self.n_users) if (user_begin == 0 and user_end == 0) else (user_begin, user_end)
 
     def close(self):
@@ -237,6 +238,10 @@ class Engine:
         _check(lib().rec_eval_sampled_per_user(self.handle, C.c_int(topn), C.c_int32(n_sampled), C.c_uint64(seed), C.byref(m),
                                                _p(counts), _p(draws)))
         return m, counts, draws
+
+    def project_rows(self):
+        """TransRec: every item row back onto the unit ball (what an update launch does unless "project_after_launch" is 0)."""
+        _check(lib().rec_project_rows(self.handle))
 
     def eval_topk(self, users, k=50):
         users = np.ascontiguousarray(users, np.int32)

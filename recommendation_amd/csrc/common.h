@@ -101,7 +101,10 @@ int launch_sgd_wide(const DevModel& m, const int4* tuples, const int64_t* qoff, 
 size_t partition_scratch_bytes(int64_t n, int slices);
 int launch_partition_by_slice(const int4* src, int4* dst, int64_t n, int field, int slice_rows, int slices, void* scratch,
                               int64_t* qoff, hipStream_t st, int tile = 0);
-int launch_apply_global(const DevModel& m, int precision, double lr, int64_t n_tuples, double cap, hipStream_t st);
+// TransRec after a launch: the gradient sum of the global translation r folded in, and (project) every item row back onto
+// the unit ball (TransRec.cpp:245-258); launch_project_rows: the second part alone
+int launch_apply_global(const DevModel& m, int precision, double lr, int64_t n_tuples, double cap, hipStream_t st, bool project = true);
+int launch_project_rows(const DevModel& m, int precision, hipStream_t st);
 // max_in_flight: upper bound on the tuples being worked on at the same time (0 = as many as the chip holds).
 // batch (1, 2, 4, 8): the tuples come in aligned groups of `batch` consecutive tuples of one user; one wavefront
 // walks a group's shared history once.

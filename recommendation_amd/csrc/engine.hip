@@ -69,6 +69,8 @@ struct rec_engine {
     double ms[4] = {0, 0, 0, 0};
     int64_t launches[4] = {0, 0, 0, 0};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[4];
+    std::vector<void*> round_base;   // rec_shards_begin_round: a copy of every table that is not indexed by user
+    int project_after_launch = 1;    // TransRec: every item row is projected onto the unit ball after each update launch
 };
 
 // Tuple staging of rec_sgd_replay_static: lives in the code object, so that entry point never allocates.  One copy per
@@ -693,7 +695,7 @@ static int launch_update(rec_engine* e, const int4* tuples, int64_t n, double lr
                                    : launch_sgd_owner(e->dm, e->desc.precision, dst, e->qoff_dev, len, lr, e->atomic, e->owner_flush, e->st);
             if (rc) return rc;
             if (global_row) {
-                if ((rc = launch_apply_global(e->dm, e->desc.precision, lr, len, (double)e->global_cap, e->st))) return rc;
+                if ((rc = launch_apply_global(e->dm, e->desc.precision, lr, len, (double)e->global_cap, e->st, e->project_after_launch != 0))) return rc;
             }
             continue;
         }
@@ -1041,6 +1043,192 @@ extern "C" int rec_eval_topk(rec_engine* e, const int32_t* users, int32_t n_user
     return eval_topk(e->dm, e->desc.precision, users, n_users, k, items_out, scores_out, e->st);
 }
 
+// ------------------------------------------------------------------------------------------------
+// User-sharded training inside one process: N engines with consecutive user ranges, on one device (all of them) or on
+// N different devices.  A round = every shard applies its share of tuples to its own replica of the item tables, then
+//     table = base + sum_r (table_r - base)          (base: the common value at the start of the round)
+// is formed and written to every replica: rec_shards_begin_round keeps the base, rec_shards_combine forms the sum -
+// in one kernel when the shards share a device, else as delta_r = table_r - base, one RCCL all-reduce (sum) per table
+// over the shards' devices, table_r = base + sum.  RCCL is loaded when the first multi-device combine needs it.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+namespace {
+struct ShardPtrs { void* tab[16]; };
+template <class T>
+__global__ void shard_combine_local_kernel(ShardPtrs p, const T* __restrict__ base, int n_shards, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const T b = base[i];
+        T s = b;
+        for (int r = 0; r < n_shards; r++) s += ((const T*)p.tab[r])[i] - b;
+        for (int r = 0; r < n_shards; r++) ((T*)p.tab[r])[i] = s;
+    }
+}
+template <class T>
+__global__ void shard_axpy_kernel(T* __restrict__ tab, const T* __restrict__ base, T sign, int64_t n)   // tab += sign * base
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) tab[i] += sign * base[i];
+}
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::vector<int> devs; std::vector<ncclComm_t> comms;   // the communicators of the last device list (kept until the process ends)
+};
+Rccl g_rccl;
+std::mutex g_rccl_mutex;
+int rccl_comms(const std::vector<int>& devs, ncclComm_t** out)
+{
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    Rccl& r = g_rccl;
+    if (!r.lib) {
+        r.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!r.lib) r.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!r.lib) { rec_set_error(std::string("shards on several devices need RCCL: ") + dlerror()); return -2; }
+        r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.lib, "ncclCommInitAll");
+        r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
+        r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
+        r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+        if (!r.CommInitAll || !r.AllReduce || !r.GroupStart || !r.GroupEnd || !r.GetErrorString) { rec_set_error("librccl lacks an expected symbol"); r.lib = nullptr; return -2; }
+    }
+    if (r.devs != devs) {
+        r.comms.assign(devs.size(), nullptr);
+        const ncclResult_t rc = r.CommInitAll(r.comms.data(), (int)devs.size(), devs.data());
+        if (rc != ncclSuccess) { rec_set_error(std::string("ncclCommInitAll: ") + r.GetErrorString(rc)); r.devs.clear(); return -2; }
+        r.devs = devs;
+    }
+    *out = r.comms.data();
+    return 0;
+}
+int check_shards(rec_engine* const* shards, int n, bool* one_device)
+{
+    if (!shards || n < 1 || n > 16) { rec_set_error("1..16 shards"); return -1; }
+    for (int r = 0; r < n; r++) {
+        if (!shards[r]) { rec_set_error("null shard"); return -1; }
+        if (shards[r]->nw != shards[0]->nw || shards[r]->desc.model != shards[0]->desc.model || shards[r]->desc.precision != shards[0]->desc.precision ||
+            shards[r]->tables.size() != shards[0]->tables.size()) { rec_set_error("the shards are not engines of one model"); return -1; }
+    }
+    bool same = true, distinct = true;
+    for (int r = 0; r < n; r++)
+        for (int q = 0; q < r; q++) { if (shards[r]->desc.device != shards[q]->desc.device) same = false; else distinct = false; }
+    if (n > 1 && !same && !distinct) { rec_set_error("shards must share one device or sit on one device each"); return -1; }
+    *one_device = same;
+    return 0;
+}
+}  // namespace
+
+extern "C" int rec_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { rec_set_error("hipGetDeviceCount failed"); return -1; }
+    return n;
+}
+
+extern "C" int rec_shards_begin_round(rec_engine* const* shards, int n)
+{
+    bool one_device;
+    if (int rc = check_shards(shards, n, &one_device)) return rc;
+    // The projection of TransRec's item rows is not additive: done by every shard after its launches it would enter the
+    // sum of deltas once per shard (a row outside the ball is pulled back N times over and overshoots).  The shards'
+    // launches only add gradient steps (rows are projected as they are read); the combined table is projected once.
+    for (int r = 0; r < n; r++) shards[r]->project_after_launch = 0;
+    // shards on one device hold the same values between rounds: the first one's copy serves all of them
+    for (int r = 0; r < (one_device ? 1 : n); r++) {
+        rec_engine* e = shards[r];
+        ENG_HIP(hipSetDevice(e->desc.device));
+        if (e->round_base.empty())
+            for (const TableDesc& t : e->tables) {
+                void* p = nullptr;
+                if (!t.is_user) { ENG_HIP(hipMalloc(&p, (size_t)std::max<int64_t>(t.rows * t.cols, 1) * e->elem_size)); e->owned.push_back(p); }
+                e->round_base.push_back(p);
+            }
+        for (size_t t = 0; t < e->tables.size(); t++)
+            if (!e->tables[t].is_user)
+                ENG_HIP(hipMemcpyAsync(e->round_base[t], (char*)e->W + e->tables[t].dev_off * e->elem_size, (size_t)(e->tables[t].rows * e->tables[t].cols) * e->elem_size,
+                                       hipMemcpyDeviceToDevice, e->st));
+    }
+    if (one_device) {
+        // the other shards' streams must not start the round before the copy has been taken
+        ENG_HIP(hipStreamSynchronize(shards[0]->st));
+    }
+    return 0;
+}
+
+extern "C" int rec_shards_combine(rec_engine* const* shards, int n)
+{
+    bool one_device;
+    if (int rc = check_shards(shards, n, &one_device)) return rc;
+    if (n == 1) return 0;
+    rec_engine* e0 = shards[0];
+    const bool f32 = e0->desc.precision == REC_F32;
+    for (int r = 0; r < (one_device ? 1 : n); r++)
+        if (shards[r]->round_base.empty()) { rec_set_error("rec_shards_combine without rec_shards_begin_round"); return -1; }
+    if (one_device) {
+        ENG_HIP(hipSetDevice(e0->desc.device));
+        for (int r = 0; r < n; r++) ENG_HIP(hipStreamSynchronize(shards[r]->st));
+        for (size_t t = 0; t < e0->tables.size(); t++) {
+            if (e0->tables[t].is_user) continue;
+            const int64_t cnt = e0->tables[t].rows * e0->tables[t].cols;
+            ShardPtrs p = {};
+            for (int r = 0; r < n; r++) p.tab[r] = (char*)shards[r]->W + shards[r]->tables[t].dev_off * e0->elem_size;
+            const unsigned blocks = (unsigned)std::min<int64_t>(4096, (cnt + 255) / 256);
+            if (f32) hipLaunchKernelGGL(shard_combine_local_kernel<float>, dim3(blocks), dim3(256), 0, e0->st, p, (const float*)e0->round_base[t], n, cnt);
+            else hipLaunchKernelGGL(shard_combine_local_kernel<double>, dim3(blocks), dim3(256), 0, e0->st, p, (const double*)e0->round_base[t], n, cnt);
+        }
+        ENG_HIP(hipGetLastError());
+        ENG_HIP(hipStreamSynchronize(e0->st));
+        for (int r = 0; r < n; r++) { if (int rc = launch_project_rows(shards[r]->dm, shards[r]->desc.precision, shards[r]->st)) return rc; }
+        for (int r = 0; r < n; r++) ENG_HIP(hipStreamSynchronize(shards[r]->st));
+        return 0;
+    }
+    std::vector<int> devs(n);
+    for (int r = 0; r < n; r++) devs[r] = shards[r]->desc.device;
+    ncclComm_t* comms = nullptr;
+    if (int rc = rccl_comms(devs, &comms)) return rc;
+    for (size_t t = 0; t < e0->tables.size(); t++) {
+        if (e0->tables[t].is_user) continue;
+        const int64_t cnt = e0->tables[t].rows * e0->tables[t].cols;
+        const unsigned blocks = (unsigned)std::min<int64_t>(4096, (cnt + 255) / 256);
+        for (int pass = 0; pass < 3; pass++) {
+            if (pass == 1) { const ncclResult_t rc = g_rccl.GroupStart(); if (rc != ncclSuccess) { rec_set_error(std::string("ncclGroupStart: ") + g_rccl.GetErrorString(rc)); return -2; } }
+            for (int r = 0; r < n; r++) {
+                rec_engine* e = shards[r];
+                ENG_HIP(hipSetDevice(e->desc.device));
+                void* tab = (char*)e->W + e->tables[t].dev_off * e->elem_size;
+                if (pass == 1) {
+                    const ncclResult_t rc = g_rccl.AllReduce(tab, tab, (size_t)cnt, f32 ? ncclFloat32 : ncclFloat64, ncclSum, comms[r], e->st);
+                    if (rc != ncclSuccess) { rec_set_error(std::string("ncclAllReduce: ") + g_rccl.GetErrorString(rc)); (void)g_rccl.GroupEnd(); return -2; }
+                } else {
+                    // pass 0: table -= base (this shard's delta); pass 2: table += base
+                    if (f32) hipLaunchKernelGGL(shard_axpy_kernel<float>, dim3(blocks), dim3(256), 0, e->st, (float*)tab, (const float*)e->round_base[t], pass == 0 ? -1.f : 1.f, cnt);
+                    else hipLaunchKernelGGL(shard_axpy_kernel<double>, dim3(blocks), dim3(256), 0, e->st, (double*)tab, (const double*)e->round_base[t], pass == 0 ? -1.0 : 1.0, cnt);
+                    ENG_HIP(hipGetLastError());
+                }
+            }
+            if (pass == 1) { const ncclResult_t rc = g_rccl.GroupEnd(); if (rc != ncclSuccess) { rec_set_error(std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(rc)); return -2; } }
+        }
+    }
+    for (int r = 0; r < n; r++) {
+        ENG_HIP(hipSetDevice(shards[r]->desc.device));
+        if (int rc = launch_project_rows(shards[r]->dm, shards[r]->desc.precision, shards[r]->st)) return rc;
+    }
+    for (int r = 0; r < n; r++) { ENG_HIP(hipSetDevice(shards[r]->desc.device)); ENG_HIP(hipStreamSynchronize(shards[r]->st)); }
+    return 0;
+}
+
+extern "C" int rec_project_rows(rec_engine* e)
+{
+    if (!e) { rec_set_error("null engine"); return -1; }
+    ENG_HIP(hipSetDevice(e->desc.device));
+    if (int rc = launch_project_rows(e->dm, e->desc.precision, e->st)) return rc;
+    ENG_HIP(hipStreamSynchronize(e->st));
+    return 0;
+}
+
 extern "C" int rec_num_tables(const rec_engine* e) { return e ? (int)e->tables.size() : -1; }
 
 extern "C" int rec_table_info(const rec_engine* e, int t, void** dev_ptr, int64_t* rows, int64_t* cols, int* is_user_table)
@@ -1092,6 +1280,7 @@ extern "C" int rec_set_option(rec_engine* e, const char* name, int64_t value)
         e->pos_share = (int)value;
     }
     else if (s == "share_negative") { if (value != 1 && value != 2 && value != 4) { rec_set_error("share_negative must be 1, 2 or 4"); return -1; } e->neg_share = (int)value; }
+    else if (s == "project_after_launch") e->project_after_launch = value != 0;
     else if (s == "pair_min_history") { if (value < 0 || value > (1 << 20)) { rec_set_error("pair_min_history must be in 0..2^20"); return -1; } e->dm.pair_min_hist = (int)value; }
     else if (s == "user_batch") { if (value != 1 && value != 2 && value != 4 && value != 8) { rec_set_error("user_batch must be 1, 2, 4 or 8"); return -1; } e->user_batch = (int)value; }
     else if (s == "wide") { if (value != 0 && value != 1) { rec_set_error("wide must be 0 or 1"); return -1; } e->wide = (int)value; }

@@ -473,18 +473,22 @@ int launch_sgd_owner(const DevModel& m, int precision, const int4* partitioned, 
                                 : dispatch_model<float>(m, partitioned, n, lr, atomic, qoff, flush_at, st);
 }
 
-int launch_apply_global(const DevModel& m, int precision, double lr, int64_t n_tuples, double cap, hipStream_t st)
+int launch_apply_global(const DevModel& m, int precision, double lr, int64_t n_tuples, double cap, hipStream_t st, bool project)
+{
+    if (!(m.model == REC_TRANSREC || m.model == REC_TRANSREC_L1)) return 0;
+    if (precision == REC_F64) hipLaunchKernelGGL(apply_global_kernel<double>, dim3(1), dim3(256), 0, st, m, lr, n_tuples, cap);
+    else hipLaunchKernelGGL(apply_global_kernel<float>, dim3(1), dim3(256), 0, st, m, (float)lr, n_tuples, (float)cap);
+    HIP_TRY(hipGetLastError());
+    return project ? launch_project_rows(m, precision, st) : 0;
+}
+
+int launch_project_rows(const DevModel& m, int precision, hipStream_t st)
 {
     if (!(m.model == REC_TRANSREC || m.model == REC_TRANSREC_L1)) return 0;
     int64_t blocks = ((int64_t)m.I + 3) / 4;
     if (blocks > 4096) blocks = 4096;
-    if (precision == REC_F64) {
-        hipLaunchKernelGGL(apply_global_kernel<double>, dim3(1), dim3(256), 0, st, m, lr, n_tuples, cap);
-        hipLaunchKernelGGL(project_rows_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, st, (double*)m.tab[TR_H], (int64_t)m.I, m.K);
-    } else {
-        hipLaunchKernelGGL(apply_global_kernel<float>, dim3(1), dim3(256), 0, st, m, (float)lr, n_tuples, (float)cap);
-        hipLaunchKernelGGL(project_rows_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (float*)m.tab[TR_H], (int64_t)m.I, m.K);
-    }
+    if (precision == REC_F64) hipLaunchKernelGGL(project_rows_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, st, (double*)m.tab[TR_H], (int64_t)m.I, m.K);
+    else hipLaunchKernelGGL(project_rows_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (float*)m.tab[TR_H], (int64_t)m.I, m.K);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -22,7 +22,7 @@ static double clock_()
 }
 
 // ---------------------------------------------------------------------------------------- model
-model::model(corpus* corp) : NW(0), W(0), bestW(0), corp(corp), eng(0), epoch_counter(0), best_on_device(false)
+model::model(corpus* corp) : NW(0), W(0), bestW(0), corp(corp), eng(0), rounds_per_epoch(1), epoch_counter(0), best_on_device(false)
 {
     nUsers = corp->nUsers; nItems = corp->nItems; nClicks = corp->nClicks;
     clicked_per_user.resize(nUsers);
@@ -83,33 +83,115 @@ void model::createEngine(rec_model_desc desc, const vector<int64_t>* path_off, c
     desc.precision = (p && strcmp(p, "f64") == 0) ? REC_F64 : REC_F32;
     const char* dv = getenv("RECSYS_DEVICE");
     desc.device = dv ? atoi(dv) : 0;
-    desc.user_begin = desc.user_end = 0;
     best_on_device = false;
-    check(rec_create(&c, &desc, &eng));
+    userless_tuples = desc.model == REC_MC;
+    // RECSYS_SHARDS=N: user-sharded training inside this process (N <= 16).  Shard r holds users [U r / N, U (r+1) / N)
+    // and sits on GPU r when the process sees at least N GPUs (RECSYS_SHARDS_ONE_DEVICE=1: all on RECSYS_DEVICE).
+    const char* ns = getenv("RECSYS_SHARDS");
+    int n_shards = ns ? atoi(ns) : 1;
+    if (n_shards < 1) n_shards = 1;
+    if (n_shards > 16) n_shards = 16;
+    if (n_shards > nUsers) n_shards = nUsers > 0 ? nUsers : 1;
+    const char* od = getenv("RECSYS_SHARDS_ONE_DEVICE");
+    const bool spread = n_shards > 1 && !(od && atoi(od) != 0) && rec_device_count() >= n_shards;
+    shards.assign(n_shards, (rec_engine*)0);
+    for (int r = 0; r < n_shards; r++) {
+        rec_model_desc d = desc;
+        d.user_begin = n_shards > 1 ? (int)((int64_t)nUsers * r / n_shards) : 0;
+        d.user_end = n_shards > 1 ? (int)((int64_t)nUsers * (r + 1) / n_shards) : 0;
+        if (spread) d.device = r;
+        check(rec_create(&c, &d, &shards[r]));
+    }
+    eng = shards[0];
     NW = rec_nw(eng);
+    // rounds per epoch: an item row receives about 4 updates per round (every step updates a positive's and a negative's
+    // row); longer rounds cost accuracy, measured against the reference's trajectories
+    const int64_t steps = rec_steps_per_epoch(eng);
+    rounds_per_epoch = n_shards > 1 ? (int)std::max<int64_t>(1, (steps + 2 * (int64_t)nItems - 1) / (2 * (int64_t)std::max(nItems, 1))) : 1;
+    const char* rp = getenv("RECSYS_SHARD_ROUNDS");
+    if (rp && atoi(rp) > 0) rounds_per_epoch = atoi(rp);
+    if (n_shards > 1)
+        printf("  \"shards\": %d, \"devices\": %d, \"rounds per epoch\": %d\n", n_shards, spread ? n_shards : 1, rounds_per_epoch);
     W = new double[NW > 0 ? NW : 1];
     bestW = new double[NW > 0 ? NW : 1];
 }
 
 void model::destroyEngine()
 {
-    if (eng) { rec_destroy(eng); eng = 0; }
+    for (size_t r = 0; r < shards.size(); r++) if (shards[r]) rec_destroy(shards[r]);
+    shards.clear();
+    eng = 0;
     best_on_device = false;
 }
 
-void model::syncToHost() { if (eng && NW > 0) check(rec_params_download(eng, W, NW)); }
-void model::syncToDevice() { if (eng && NW > 0) check(rec_params_upload(eng, W, NW)); }
+// one updateFactors call; with shards: on the shard that holds the user's rows (MC, whose tuples name no user: the first),
+// as a round of its own so that every replica of the item tables receives the step
+void model::replayOne(const int32_t* t, double learn_rate)
+{
+    if (shards.size() == 1) { check(rec_sgd_replay(eng, learn_rate, t, 1, REC_REPLAY_SEQUENTIAL)); return; }
+    check(rec_shards_begin_round(shards.data(), (int)shards.size()));
+    check(rec_sgd_replay(userless_tuples ? shards[0] : shardOf(t[0]), learn_rate, t, 1, REC_REPLAY_SEQUENTIAL));
+    check(rec_shards_combine(shards.data(), (int)shards.size()));
+}
+
+void model::initParams() { for (size_t r = 0; r < shards.size(); r++) check(rec_params_init(shards[r], 0)); }
+
+rec_engine* model::shardOf(int user) const
+{
+    const int n = (int)shards.size();
+    for (int r = 0; r < n; r++)
+        if (user < (int)((int64_t)nUsers * (r + 1) / n)) return shards[r];
+    return shards[n - 1];
+}
+
+// every shard moves the tables that are not indexed by user (the same values everywhere) and its own users' rows
+void model::syncToHost() { if (NW > 0) for (size_t r = 0; r < shards.size(); r++) check(rec_params_download(shards[r], W, NW)); }
+void model::syncToDevice() { if (NW > 0) for (size_t r = 0; r < shards.size(); r++) check(rec_params_upload(shards[r], W, NW)); }
 
 void model::epoch(double learn_rate)
 {
-    check(rec_sgd_epoch(eng, learn_rate, rec_steps_per_epoch(eng), 0, epoch_counter++));
-    check(rec_sync(eng));
+    const int n = (int)shards.size();
+    if (n == 1) {
+        check(rec_sgd_epoch(eng, learn_rate, rec_steps_per_epoch(eng), 0, epoch_counter++));
+        check(rec_sync(eng));
+        return;
+    }
+    const int64_t per_round = rec_steps_per_epoch(eng) / ((int64_t)n * rounds_per_epoch);
+    for (int k = 0; k < rounds_per_epoch; k++) {
+        check(rec_shards_begin_round(shards.data(), n));
+        // a different tuple stream for every (epoch, round, shard); the launches only enqueue, so shards on different GPUs run side by side
+        for (int r = 0; r < n; r++)
+            check(rec_sgd_epoch(shards[r], learn_rate, per_round, 0, (epoch_counter * rounds_per_epoch + k) * n + r));
+        check(rec_shards_combine(shards.data(), n));
+    }
+    epoch_counter++;
+}
+
+// the metrics of all shards' users from the 8 sums of each (variance as E[x^2] - mean^2: rounding apart, model.cpp:91-97)
+static void sharded_metrics(const std::vector<rec_engine*>& shards, int topn, rec_metrics* m, int (*checker)(int))
+{
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t r = 0; r < shards.size(); r++) {
+        double part[8];
+        checker(rec_eval_sums(shards[r], topn, part));
+        for (int i = 0; i < 8; i++) s[i] += part[i];
+    }
+    const double n = s[7];
+    m->n_users = (int64_t)n;
+    m->auc_val = s[0] / n; m->auc_test = s[1] / n; m->hit_val = s[2] / n; m->hit_test = s[3] / n;
+    m->mrr_val = s[4] / n; m->mrr_test = s[5] / n; m->var_test = s[6] / n - m->auc_test * m->auc_test;
+}
+static int exit_on_error(int rc)
+{
+    if (rc != 0) { printf("engine error: %s\n", rec_last_error()); exit(1); }
+    return rc;
 }
 
 void model::AUC(double* AUC_val, double* AUC_test, double* HIT_val, double* HIT_test, double* MRR_val, double* MRR_test, double* var)
 {
     rec_metrics m;
-    check(rec_eval(eng, 50, &m, 0, 0));
+    if (shards.size() > 1) sharded_metrics(shards, 50, &m, exit_on_error);
+    else check(rec_eval(eng, 50, &m, 0, 0));
     *AUC_val = m.auc_val; *AUC_test = m.auc_test; *HIT_val = m.hit_val; *HIT_test = m.hit_test;
     *MRR_val = m.mrr_val; *MRR_test = m.mrr_test; *var = m.var_test;
 }
@@ -122,8 +204,9 @@ void model::sampleAUC(double* AUC_val, double* AUC_test, double* var)
 {
     rec_metrics m;
     const char* sampled = getenv("RECSYS_SAMPLED_VALIDATION");
-    const int mode = sampled ? atoi(sampled) : 0;
-    if (mode == 1) check(rec_eval_sampled_per_user(eng, 50, 2000, validation_calls++, &m, 0, 0));
+    const int mode = (sampled && shards.size() == 1) ? atoi(sampled) : 0;   // sharded runs validate on the exact value
+    if (shards.size() > 1) sharded_metrics(shards, 50, &m, exit_on_error);
+    else if (mode == 1) check(rec_eval_sampled_per_user(eng, 50, 2000, validation_calls++, &m, 0, 0));
     else if (mode == 2) check(rec_eval_sampled(eng, 50, 2000, validation_calls++, &m, 0, 0));
     else check(rec_eval(eng, 50, &m, 0, 0));
     *AUC_val = m.auc_val; *AUC_test = m.auc_test; *var = m.var_test;
@@ -132,7 +215,9 @@ void model::sampleAUC(double* AUC_val, double* AUC_test, double* var)
 void model::MultipleMetrics(int topN, bool sample, double& valid)
 {
     rec_metrics m;
-    if (sample && nUsers > 50000) {
+    if (shards.size() > 1) {
+        sharded_metrics(shards, topN, &m, exit_on_error);
+    } else if (sample && nUsers > 50000) {
         // src/model.cpp:260: above 50000 users each valid user is kept with probability ~50000 / nUsers (same rand() test);
         // every user is scored on the device, the subsample is taken from the per-user counts
         std::vector<int32_t> counts((size_t)nUsers * 3);
@@ -162,7 +247,7 @@ void model::MultipleMetrics(int topN, bool sample, double& valid)
 
 void model::copyBestModel()
 {
-    check(rec_snapshot_best(eng));
+    for (size_t r = 0; r < shards.size(); r++) check(rec_snapshot_best(shards[r]));
     best_on_device = true;
 }
 
@@ -218,7 +303,7 @@ void model::trainLoop(int iterations, double learn_rate, int cadence, int first_
     }
     // "copy back best parameters" (e.g. BPRMF.cpp:189-191).  Without any validation the reference copies an
     // uninitialised bestW (undefined behaviour); here the trained parameters are kept instead.
-    if (best_on_device) check(rec_restore_best(eng));
+    if (best_on_device) for (size_t r = 0; r < shards.size(); r++) check(rec_restore_best(shards[r]));
     double AUC_val, AUC_test, HIT_val, HIT_test, MRR_val, MRR_test, var;
     AUC(&AUC_val, &AUC_test, &HIT_val, &HIT_test, &MRR_val, &MRR_test, &var);
     printf("\n\n <<< %s >>> Test AUC = %f, Val AUC = %f, Test var = %f\n", toString().c_str(), AUC_test, AUC_val, var);
@@ -238,7 +323,7 @@ static rec_model_desc make_desc(int model, int K, int KK, int L, double lambda, 
 #define REPLAY1(a, b, c, d)                                                          \
     do {                                                                             \
         int32_t t_[4] = {(int32_t)(a), (int32_t)(b), (int32_t)(c), (int32_t)(d)};    \
-        check(rec_sgd_replay(eng, learn_rate, t_, 1, REC_REPLAY_SEQUENTIAL));        \
+        replayOne(t_, learn_rate);                                                   \
     } while (0)
 
 // ---------------------------------------------------------------------------------------- MostPopular
@@ -248,35 +333,35 @@ MostPopular::MostPopular(corpus* corp) : model(corp)
 }
 
 // ---------------------------------------------------------------------------------------- BPRMF
-void BPRMF::init() { createEngine(make_desc(REC_BPRMF, K, K, 1, lambda, bias_reg, 0, 0, 0)); check(rec_params_init(eng, 0)); }
+void BPRMF::init() { createEngine(make_desc(REC_BPRMF, K, K, 1, lambda, bias_reg, 0, 0, 0)); initParams(); }
 void BPRMF::cleanUp() { destroyEngine(); delete[] W; delete[] bestW; W = bestW = 0; }
 void BPRMF::train(int iterations, double learn_rate) { trainLoop(iterations, learn_rate, 50, 0, 300, false); }
 void BPRMF::updateFactors(int user_id, int pos_item_id, int neg_item_id, double learn_rate) { REPLAY1(user_id, pos_item_id, neg_item_id, 0); }
 string BPRMF::toString() { char s[1000]; sprintf(s, "BPR-MF__K_%d_lambda_%f_biasReg_%f", K, lambda, bias_reg); return s; }
 
 // ---------------------------------------------------------------------------------------- MC
-void MC::init() { createEngine(make_desc(REC_MC, K, K, 1, lambda, 0, 0, 0, 0)); check(rec_params_init(eng, 0)); }
+void MC::init() { createEngine(make_desc(REC_MC, K, K, 1, lambda, 0, 0, 0, 0)); initParams(); }
 void MC::cleanUp() { destroyEngine(); delete[] W; delete[] bestW; W = bestW = 0; }
 void MC::train(int iterations, double learn_rate) { trainLoop(iterations, learn_rate, 50, 0, 1000, false); }   // MC.cpp:182
 void MC::updateFactors(int item_id, int pos_item_id, int neg_item_id, double learn_rate) { REPLAY1(item_id, pos_item_id, neg_item_id, 0); }
 string MC::toString() { char s[100]; sprintf(s, "MC__K_%d_lambda_%f", K, lambda); return s; }
 
 // ---------------------------------------------------------------------------------------- FPMC
-void FPMC::init() { createEngine(make_desc(REC_FPMC, K, KK, 1, lambda, 0, 0, 0, 0)); check(rec_params_init(eng, 0)); }
+void FPMC::init() { createEngine(make_desc(REC_FPMC, K, KK, 1, lambda, 0, 0, 0, 0)); initParams(); }
 void FPMC::cleanUp() { destroyEngine(); delete[] W; delete[] bestW; W = bestW = 0; }
 void FPMC::train(int iterations, double learn_rate) { trainLoop(iterations, learn_rate, 50, 0, 300, false); }
 void FPMC::updateFactors(int user_id, int item_id, int pos_item_id, int neg_item_id, double learn_rate) { REPLAY1(user_id, item_id, pos_item_id, neg_item_id); }
 string FPMC::toString() { char s[100]; sprintf(s, "FPMC__K_%d_KK_%d_lambda_%f", K, KK, lambda); return s; }
 
 // ---------------------------------------------------------------------------------------- PRME
-void PRME::init() { createEngine(make_desc(REC_PRME, K, KK, 1, lambda, 0, 0, alpha, 0)); check(rec_params_init(eng, 0)); }
+void PRME::init() { createEngine(make_desc(REC_PRME, K, KK, 1, lambda, 0, 0, alpha, 0)); initParams(); }
 void PRME::cleanUp() { destroyEngine(); delete[] W; delete[] bestW; W = bestW = 0; }
 void PRME::train(int iterations, double learn_rate) { trainLoop(iterations, learn_rate, 50, 0, 300, false); }
 void PRME::updateFactors(int user_id, int item_id, int pos_item_id, int neg_item_id, double learn_rate) { REPLAY1(user_id, item_id, pos_item_id, neg_item_id); }
 string PRME::toString() { char s[100]; sprintf(s, "PRME__K_%d_KK_%d_alpha_%f_lambda_%f", K, KK, alpha, lambda); return s; }
 
 // ---------------------------------------------------------------------------------------- HRM
-void HRM_avg::init() { createEngine(make_desc(modelId(), K, K, 1, lambda, 0, 0, 0, 0)); check(rec_params_init(eng, 0)); }
+void HRM_avg::init() { createEngine(make_desc(modelId(), K, K, 1, lambda, 0, 0, 0, 0)); initParams(); }
 void HRM_avg::cleanUp() { destroyEngine(); delete[] W; delete[] bestW; W = bestW = 0; }
 void HRM_avg::train(int iterations, double learn_rate) { trainLoop(iterations, learn_rate, 50, 0, 300, false); }
 void HRM_avg::updateFactors(int user, int prev_item, int item, double learn_rate)
@@ -289,7 +374,7 @@ string HRM_avg::toString() { char s[100]; sprintf(s, "HRM_AvgPooling_BPR_K_%d_la
 string HRM_max::toString() { char s[100]; sprintf(s, "HRM_MaxPooling_BPR_K_%d_lambda_%f", K, lambda); return s; }
 
 // ---------------------------------------------------------------------------------------- TransRec
-void TransRec::init() { createEngine(make_desc(modelId(), K, K, 1, lambda, bias_reg, relation_reg, 0, 0)); check(rec_params_init(eng, 0)); }
+void TransRec::init() { createEngine(make_desc(modelId(), K, K, 1, lambda, bias_reg, relation_reg, 0, 0)); initParams(); }
 void TransRec::cleanUp() { destroyEngine(); delete[] W; delete[] bestW; W = bestW = 0; }
 void TransRec::train(int iterations, double learn_rate) { trainLoop(iterations, learn_rate, 50, 0, 300, false); }
 void TransRec::updateFactors(int user, int x, int y, int yn, double learn_rate) { REPLAY1(user, x, y, yn); }
@@ -304,7 +389,7 @@ void TransRec::afterEpoch(int iter)
     for (int k = 0; k < K; k++) printf("%f  ", v[k]);
     printf("\n");
     int rand_u = rand() % nUsers;
-    check(rec_params_read(eng, (int64_t)nItems + (int64_t)nItems * K + (int64_t)rand_u * K, K, v.data()));
+    check(rec_params_read(shardOf(rand_u), (int64_t)nItems + (int64_t)nItems * K + (int64_t)rand_u * K, K, v.data()));
     printf("R[u] = ");
     for (int k = 0; k < K; k++) printf("%f  ", v[k]);
     printf("\n");
@@ -313,14 +398,14 @@ string TransRec::toString() { char s[200]; sprintf(s, "TransRec__K_%d_lambda_%f_
 string TransRec_L1::toString() { char s[200]; sprintf(s, "TransRec_L1__K_%d_lambda_%f_relationReg_%f_biasReg_%f", K, lambda, relation_reg, bias_reg); return s; }
 
 // ---------------------------------------------------------------------------------------- FossilSimple
-void FossilSimple::init() { createEngine(make_desc(REC_FOSSIL_SIMPLE, K, K, 1, lambda, bias_reg, 0, 0, 0)); check(rec_params_init(eng, 0)); }
+void FossilSimple::init() { createEngine(make_desc(REC_FOSSIL_SIMPLE, K, K, 1, lambda, bias_reg, 0, 0, 0)); initParams(); }
 void FossilSimple::cleanUp() { destroyEngine(); delete[] W; delete[] bestW; W = bestW = 0; }
 void FossilSimple::train(int iterations, double learn_rate) { trainLoop(iterations, learn_rate, 50, 0, 500, false); }   // FossilSimple.cpp:302
 void FossilSimple::updateFactors(int user_id, int item_id, int pos_item_id, int neg_item_id, double learn_rate) { REPLAY1(user_id, item_id, pos_item_id, neg_item_id); }
 string FossilSimple::toString() { char s[100]; sprintf(s, "FossilSimple__K_%d_lambda_%.2f_biasReg_%.2f", K, lambda, bias_reg); return s; }
 
 // ---------------------------------------------------------------------------------------- Fossil
-void Fossil::init() { createEngine(make_desc(REC_FOSSIL, K, K, L, lambda, bias_reg, 0, 0, dataset_factor)); check(rec_params_init(eng, 0)); }
+void Fossil::init() { createEngine(make_desc(REC_FOSSIL, K, K, L, lambda, bias_reg, 0, 0, dataset_factor)); initParams(); }
 void Fossil::cleanUp() { destroyEngine(); delete[] W; delete[] bestW; W = bestW = 0; }
 void Fossil::train(int iterations, double learn_rate) { trainLoop(iterations, learn_rate, 50, 0, 300, false); }
 void Fossil::beforeEpoch(int)
@@ -407,7 +492,7 @@ void REBUS::init()
                           lab_item.data(), path_off.data(), path_item.data());
     createEngine(make_desc(REC_REBUS, K, K, L, lambda, bias_reg, 0, alpha_up, 0), &path_off, &path_item);
     printf(" --NW : %lld -- \n\n", (long long)NW);
-    check(rec_params_init(eng, 0));
+    initParams();
     printf(" --Init REBUS ended -- \n\n");
 }
 void REBUS::cleanUp() { destroyEngine(); delete[] W; delete[] bestW; W = bestW = 0; }

@@ -42,9 +42,17 @@ public:
     /* engine plumbing */
     void syncToHost();                // device parameters -> W
     void syncToDevice();              // W -> device parameters
-    rec_engine* eng;
+    rec_engine* eng;                  // the engine (with RECSYS_SHARDS > 1: the first shard)
+    // RECSYS_SHARDS=N: N engines with consecutive user ranges (one per GPU when the process sees N of them, else all on
+    // one), trained in rounds of local steps + one combination of the item tables per round (rec_shards_combine)
+    std::vector<rec_engine*> shards;
+    int rounds_per_epoch;
 
 protected:
+    void initParams();                // <Model>::init's random fill, the same values on every shard
+    rec_engine* shardOf(int user) const;
+    void replayOne(const int32_t* tuple, double learn_rate);
+    bool userless_tuples;             // MC: a tuple's first component is an item
     // creates the engine for `desc` (model id, K, ... filled by the subclass) and allocates W / bestW
     void createEngine(rec_model_desc desc, const std::vector<int64_t>* path_off = nullptr, const std::vector<int32_t>* path_item = nullptr);
     void destroyEngine();

@@ -79,6 +79,12 @@ class ShardedTrainer:
         self.tabs = [] if world == 1 else eng.item_tensors(device) if hasattr(eng, "item_tensors") else item_table_tensors(eng, device)
         self.bases = [t.clone() for t in self.tabs]
         self.device = device
+        # TransRec's projection of the item rows onto the unit ball is not additive: done by every rank after its launches
+        # it would enter the sum of deltas once per rank.  The ranks' launches only add gradient steps (rows are projected
+        # as they are read); the combined table is projected once, after the all-reduce.
+        self.projects = world > 1 and getattr(eng, "model", "") in ("TransRec", "TransRec_L1")
+        if self.projects:
+            eng.set_option("project_after_launch", 0)
 
     def steps_per_round(self):
         return self.eng.steps_per_epoch // (self.world * self.rounds)
@@ -106,6 +112,8 @@ class ShardedTrainer:
             self.all_reduce_sum(t)
             t.sub_(b, alpha=float(self.world)).mul_(scale).add_(b)
         self._torch_done()
+        if self.projects:
+            self.eng.project_rows()
 
     def epoch(self, lr, seed, epoch):
         for k in range(self.rounds):
@@ -171,6 +179,9 @@ class ShardGroup:
                     for t in tr:
                         t.tabs[ti].copy_(new)
                 self.torch.cuda.synchronize()
+                for t in tr:
+                    if t.projects:
+                        t.eng.project_rows()
 
     def metrics(self, topn=50):
         s = sum(np.asarray(e.eval_sums(topn)) for e in self.engines)

@@ -143,3 +143,37 @@ def test_sampled_validation_modes_of_train(workdir):
         # the reference's estimator has a standard deviation of about 1.2e-4 on this corpus (tests/golden/ml5_sampleauc.json)
         assert p != x and abs(p[0] - x[0]) < 7e-4 and abs(p[1] - x[1]) < 7e-4, (x, p)
         assert abs(s_[0] - x[0]) < 0.03 and abs(s_[1] - x[1]) < 0.03, (x, s_)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,extra", [("BPRMF", (1, 1, 10, 0.01, 0.01, 0, 0)), ("TransRec", (1, 1, 10, 0.05, 0.01, 0.05, 0)),
+                                         ("REBUS", (2, 3, 10, 0.01, 0, 0, -0.6))])
+def test_train_with_user_shards_in_one_process(workdir, name, extra):
+    """RECSYS_SHARDS=N: train() runs N engines with consecutive user ranges (here all on the one GPU) in rounds of local
+    steps, the item tables combined after every round (rec_shards_begin_round / rec_shards_combine).  The run must train
+    like the single-engine run, validate and evaluate over all users, and save a model file whose re-scoring by the CPU
+    oracle reproduces the printed metrics (user rows gathered from their shards)."""
+    args = (f"01-Data/{ML5}.txt", 0, 0) + extra + (100, "03-Models/sh", name)
+    single = run(workdir, *args)
+    aucs = {}
+    for n in (2, 3):
+        out = run(workdir, *args, env={"RECSYS_SHARDS": str(n)})
+        assert f'"shards": {n}, "devices": 1, "rounds per epoch": ' in out
+        assert len(re.findall(r"^Iter: \d+, took ", out, flags=re.M)) == 100
+        assert len(re.findall(r"^\[Valid AUC = ", out, flags=re.M)) == (1 if name == "REBUS" else 2)
+        m = re.search(r"Test AUC = ([0-9.]+), Val AUC = ([0-9.]+)", out)
+        aucs[n] = (float(m.group(1)), float(m.group(2)))
+        h = re.search(r"Test HIT50 = ([0-9.]+), Val HIT50 = ([0-9.]+)", out)
+        saved = [f for f in os.listdir(workdir / "03-Models") if f.startswith("sh__")]
+        assert len(saved) == 1, saved
+        W = parse_saved(workdir / "03-Models" / saved[0])
+        os.remove(workdir / "03-Models" / saved[0])
+        tag = {"BPRMF": "BPRMF", "TransRec": "TransRec", "REBUS": "REBUS_mc2_L3"}[name]
+        g, model, co, ci, labels = fixture_case(tag, "ml5")
+        _, counts = make_oracle(g, model, co, ci, labels).eval(W)
+        mm = orc.metrics(counts)
+        assert abs(mm[1] - aucs[n][0]) < 3e-4 and abs(mm[0] - aucs[n][1]) < 3e-4, (n, mm[:2], aucs[n])
+        assert abs(mm[3] - float(h.group(1))) < 2e-3 and abs(mm[2] - float(h.group(2))) < 2e-3
+    m = re.search(r"Test AUC = ([0-9.]+), Val AUC = ([0-9.]+)", single)
+    for n in (2, 3):
+        assert abs(aucs[n][0] - float(m.group(1))) < 0.012 and abs(aucs[n][1] - float(m.group(2))) < 0.012, (n, aucs[n], m.groups())
