@@ -1287,7 +1287,7 @@ extern "C" int rec_set_option(rec_engine* e, const char* name, int64_t value)
     else if (s == "owner_neg") { if (value != 0 && value != 1) { rec_set_error("owner_neg must be 0 or 1"); return -1; } e->owner = (int)value; }
     else if (s == "owner_flush") { if (value < 1 || value > 65536) { rec_set_error("owner_flush must be in 1..65536"); return -1; } e->owner_flush = (int)value; }
     else if (s == "owner_per_item") { if (value < 1) { rec_set_error("owner_per_item must be positive"); return -1; } e->owner_per_item = value; }
-    else if (s == "eval_screen") { if (value != 0 && value != 1) { rec_set_error("eval_screen must be 0 or 1"); return -1; } eval_configure_screen((int)value, -1); }
+    else if (s == "eval_screen") { if (value < 0 || value > 2) { rec_set_error("eval_screen must be 0, 1 or 2"); return -1; } eval_configure_screen((int)value, -1); }
     else if (s == "eval_ranges") { if (value < 0 || value > 64) { rec_set_error("eval_ranges must be in 0..64"); return -1; } eval_configure_ranges((int)value); }
     else if (s == "eval_screen_cap") { if (value < 0 || value > 4096) { rec_set_error("eval_screen_cap must be in 0..4096"); return -1; } eval_configure_screen(-1, (int)value); }
     else if (s == "owner_slices") { if (value != 0 && value != 256 && value != 512 && value != 1024) { rec_set_error("owner_slices must be 0, 256, 512 or 1024"); return -1; } e->owner_slices = (int)value; }

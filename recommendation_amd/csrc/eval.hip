@@ -656,6 +656,329 @@ __global__ void __launch_bounds__(256, DENSE && KQ <= 64 ? 3 : 2) score_screen_k
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The f16 screen: the same provable sweep on the 16-bit matrix pipe (v_mfma_f32_16x16x32_f16: 16 times the multiply-adds
+// of the FP32 form per cycle).  Every operand is split into two halves of 11 significant bits each,
+//     x * scale = h + l + e,   h = f16(x * scale),  l = f16(x * scale - h),   |e| <= 2^-22 |x * scale| + 2^-25  (2^-14 if f16 subnormals were flushed),
+// with one power-of-two scale for the item tables and one for the queries that put their largest element in [2^13, 2^14)
+// (f16's normal range then holds the low halves of everything within 2^-17 of the largest element; below that the error
+// is an absolute one).  Products of two f16 numbers are exact in f32, so
+//     <q, T> = sum (qh Th)  +  sum (qh Tl + ql Th)  +  [ ql Tl + eq T + q eT ]
+//              main chain      cross chain (2^-11 of the main one)     dropped: <= 3.3 * 2^-22 ||q|| ||T|| + the 2^-25 floors
+// is three MFMAs per 32 contraction indices.  The two chains have accumulators of their own: the main one (KQ products
+// on top of b_j) carries the accumulation error, (KQ + 3) roundings of relative size 2^-23 at most (twice the unit
+// roundoff: the bound holds whether the matrix pipe rounds to nearest or truncates, and for any order of summation);
+// the cross chain's terms are 2^-11 of that.  The margin of a query (screen16_queries_kernel) adds these up; a column
+// whose score is further than the margin from the threshold is decided for certain, the others go to the fp64 recheck
+// exactly as in the f32 screen.  Operand maps: lane l holds A[row l & 15][k = 8 (l >> 4) + j] and B[k = 8 (l >> 4) + j]
+// [col l & 15], j = 0..7; D[row 4 (l >> 4) + r][col l & 15].
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half_t;
+
+template <int KQ> struct Screen16Shape {
+    static constexpr int MT = KQ <= 64 ? 4 : KQ <= 128 ? 2 : 1;   // 16-query tiles per wavefront
+    static constexpr int NI = KQ <= 128 ? 64 : 32;                // items per tile
+    static constexpr int QB = 4 * MT * 16;                        // queries per block
+};
+
+// power-of-two scale that puts a largest magnitude m into [2^13, 2^14); 1 when m is 0, infinite or NaN
+__device__ __forceinline__ double screen16_scale(unsigned max_bits)
+{
+    const float m = __uint_as_float(max_bits);
+    if (!(m > 0.f) || !(m < INFINITY)) return 1.0;
+    int e; (void)frexpf(m, &e);                // m = f 2^e, 0.5 <= f < 1
+    int s = 14 - e;
+    s = s < -50 ? -50 : s > 50 ? 50 : s;
+    return ldexp(1.0, s);
+}
+
+// bounds[0] = max ||T_j||, [1] = max |b_j|, [2] = max |T_jk|, [3] = max |q'_k| (bit patterns of non-negative floats)
+__global__ void __launch_bounds__(256) screen16_bounds_kernel(EvalDev ev, const float* __restrict__ seg0, const float* __restrict__ seg1, int I,
+                                                              unsigned* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int waves = (int)(((int64_t)gridDim.x * blockDim.x) >> 6);
+    unsigned nmax = 0, bmax = 0, emax = 0, qmax = 0;
+    for (int j = wave; j < I; j += waves) {
+        double s = 0; float em = 0.f;
+        for (int k = lane; k < ev.K1; k += 64) { const float t = seg0[(int64_t)j * ev.K1 + k]; s += (double)t * t; em = (fabsf(t) > em || t != t) ? fabsf(t) : em; }
+        for (int k = lane; k < ev.K2; k += 64) { const float t = seg1[(int64_t)j * ev.K2 + k]; s += (double)t * t; em = (fabsf(t) > em || t != t) ? fabsf(t) : em; }
+        s = group_sum<64>(s);
+        const float n = __double2float_ru(sqrt(s) * 1.000001), b = __double2float_ru(fabs(ev.bconst[j]) * 1.000001);
+        nmax = max(nmax, __float_as_uint(n == n ? n : INFINITY));
+        bmax = max(bmax, __float_as_uint(b == b ? b : INFINITY));
+        emax = max(emax, __float_as_uint(em == em ? em : INFINITY));
+    }
+    for (int64_t w = wave; w < ev.nq; w += waves) {
+        float qm = 0.f;
+        for (int k = lane; k < ev.KQ; k += 64) { const float q = __double2float_ru(fabs(ev.Q[w * ev.KQ + k])); qm = (q > qm || q != q) ? q : qm; }
+        qmax = max(qmax, __float_as_uint(qm == qm ? qm : INFINITY));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { emax = max(emax, (unsigned)__shfl_xor((int)emax, o, 64)); qmax = max(qmax, (unsigned)__shfl_xor((int)qmax, o, 64)); }
+    if (lane == 0) { atomicMax(out, nmax); atomicMax(out + 1, bmax); atomicMax(out + 2, emax); atomicMax(out + 3, qmax); }
+}
+
+// the two f16 halves of x (already scaled)
+__device__ __forceinline__ void split16(float x, half_t& h, half_t& l)
+{
+    h = (half_t)x;                       // round to nearest even
+    l = (half_t)(x - (float)h);          // the difference is exact in f32
+}
+
+// item planes Th, Tl [I_pad][KQ16] (zero beyond the tables' width and beyond the catalog) and the scaled constants
+// bs [I_pad] (+inf beyond the catalog: such a column is never counted and never within a margin)
+__global__ void __launch_bounds__(256) screen16_items_kernel(EvalDev ev, const float* __restrict__ seg0, const float* __restrict__ seg1, int I, int I_pad,
+                                                             int KQ16, const unsigned* __restrict__ bounds, half_t* __restrict__ Th, half_t* __restrict__ Tl,
+                                                             float* __restrict__ bs, int32_t* __restrict__ overflow)
+{
+    const double sT = screen16_scale(bounds[2]), sq = screen16_scale(bounds[3]);
+    const float sTf = (float)sT;
+    const int64_t n = (int64_t)I_pad * KQ16;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = i / KQ16; const int k = (int)(i % KQ16);
+        float x = 0.f;
+        if (j < I) { if (k < ev.K1) x = seg0[j * ev.K1 + k]; else if (k < ev.K1 + ev.K2) x = seg1[j * ev.K2 + (k - ev.K1)]; }
+        half_t h, l; split16(x * sTf, h, l);   // a power of two: the product is exact
+        Th[i] = h; Tl[i] = l;
+        if (k == 0) bs[j] = j < I ? (float)(ev.bconst[j] * (sq * sT)) : INFINITY;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // the scaled constants must stay far from the end of f32's range
+        const double bmax = (double)__uint_as_float(bounds[1]);
+        const float tm = __uint_as_float(bounds[0]), em = __uint_as_float(bounds[2]), qm = __uint_as_float(bounds[3]);
+        if (!(bmax * (sq * sT) <= 1e30) || !(tm < INFINITY) || !(em < INFINITY) || !(qm < INFINITY)) *overflow = 1;
+    }
+}
+
+// query planes Qh, Ql [nq_pad][KQ16], the scaled thresholds and the scaled margin of every query; one wavefront per query
+__global__ void __launch_bounds__(256) screen16_queries_kernel(EvalDev ev, int KQ16, const unsigned* __restrict__ bounds, half_t* __restrict__ Qh,
+                                                               half_t* __restrict__ Ql, float* __restrict__ thr_s, float* __restrict__ thr2_s,
+                                                               int32_t* __restrict__ overflow)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w >= ev.nq_pad) return;
+    const double sT = screen16_scale(bounds[2]), sq = screen16_scale(bounds[3]), S = sq * sT;
+    double s = 0;
+    for (int k = lane; k < KQ16; k += 64) {
+        const double q = k < ev.KQ ? ev.Q[w * ev.KQ + k] : 0.0;
+        s += q * q;
+        half_t h, l; split16((float)(q * sq), h, l);
+        Qh[w * KQ16 + k] = h; Ql[w * KQ16 + k] = l;
+    }
+    s = sqrt(group_sum<64>(s));
+    if (lane == 0) {
+        const double tmax = (double)__uint_as_float(bounds[0]), bmax = (double)__uint_as_float(bounds[1]);
+        const double u = 5.9604644775390625e-08;   // 2^-24
+        const double t1 = ev.thr[w], t2 = ev.nctx == 1 ? ev.thr2[w] : 0.0;
+        const double ta = (isfinite(t1) ? fabs(t1) : 0.0) + (isfinite(t2) ? fabs(t2) : 0.0);
+        const double rep = 3.3 * 4.0 * u * s * tmax;                                              // 3.3 * 2^-22: halves dropped or rounded away
+        const double sub = 6.103515625e-05 * sqrt((double)KQ16) * (tmax / sq + s / sT);          // 2^-14 per element: holds even if the matrix pipe flushed f16 subnormals (rounding alone: 2^-25)
+        const double acc = 2.0 * (KQ16 + 3) * u * (bmax + 1.002 * s * tmax) + KQ16 * (u / 64.0) * s * tmax;   // main chain; cross chain
+        const double rnd = 4.0 * u * (bmax + ta + s * tmax);                                      // thresholds and constants rounded to f32, the subtraction
+        const double mq = 1.05 * (rep + sub + acc + rnd) + 1e-30;
+        ev.qmar[w] = w < ev.nq ? __double2float_ru(mq * S * 1.000001) : 0.f;                       // a padding row decides nothing and lists nothing
+        thr_s[w] = (float)(t1 * S);
+        thr2_s[w] = (float)(t2 * S);
+        // out of f32's comfortable range, or not finite (only a padding row's -inf threshold is): the fp64 sweep takes over
+        const bool odd1 = !(isfinite(t1) ? fabs(t1 * S) <= 1e30 : (t1 < 0 && t1 == t1)), odd2 = !(isfinite(t2) ? fabs(t2 * S) <= 1e30 : (t2 < 0 && t2 == t2));
+        if (odd1 || odd2 || (w < ev.nq && !(mq * S <= 1e30))) *overflow = 1;
+    }
+}
+
+template <int KQ, bool TWO>
+__global__ void __launch_bounds__(256, 2) score_screen16_kernel(EvalDev ev, const half_t* __restrict__ Th, const half_t* __restrict__ Tl, const float* __restrict__ bs,
+                                                                const half_t* __restrict__ Qh, const half_t* __restrict__ Ql, const float* __restrict__ thr_s,
+                                                                const float* __restrict__ thr2_s, int I)
+{
+    constexpr int MT = Screen16Shape<KQ>::MT, NI = Screen16Shape<KQ>::NI, QB = Screen16Shape<KQ>::QB;
+    constexpr int NCH = KQ / 32;              // MFMA steps of 32 contraction indices
+    constexpr int STR = KQ + 8;               // halfs per tile row: KQ / 2 + 4 dwords, conflict-free 16-byte reads by 16 lanes
+    constexpr int PER = NI * KQ / 8 / 256;    // 16-byte pieces of a plane's tile per thread
+    static_assert(PER >= 1 && KQ % 32 == 0, "tile shape");
+    __shared__ __align__(16) half_t tile_h[NI * STR];
+    __shared__ __align__(16) half_t tile_l[NI * STR];
+    __shared__ float tile_b[NI];
+    __shared__ int q_amb[QB];
+    __shared__ int cnt_lds[(TWO ? 2 : 1) * QB * 16];   // counts so far per (threshold, query, column lane): registers are short
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, quad = lane >> 4;
+    const int64_t qblock = (int64_t)blockIdx.x * QB;
+    const int qw = wave * (MT * 16);
+
+    for (int i = tid; i < QB; i += 256) q_amb[i] = 0;
+    for (int i = tid; i < (TWO ? 2 : 1) * QB * 16; i += 256) cnt_lds[i] = 0;
+    // One margin for the wavefront (the largest of its queries').  Per result the epilogue forms ONE number,
+    //     y = score - (threshold - margin):   y < 0  <=>  the threshold is above the score by more than the margin: counted;
+    //                                         0 <= y <= window  <=>  the score is within the margin of the threshold: undecided,
+    // and reads both answers from y's bit pattern: the sign bit is shifted into a register of the last 32 signs (v_alignbit;
+    // their set bits are added up every 32 sub-steps), and as unsigned integers the patterns of non-negative floats order like
+    // the floats while every negative one is larger, so the smallest pattern seen (v_min3_u32) against the window's tells
+    // whether any result of the sub-step is undecided.  Equality gives y = +0: not counted, listed - the strict comparison.
+    // A padding row's threshold is -inf: y = +inf, neither.  window = 2 margin + what rounding (threshold - margin) and y can
+    // add: 2 u (|threshold| + margin) + u window.  (A compare and an add-with-carry per result were a chain through VCC with
+    // idle cycles in between, as long as the MFMAs themselves; NaN has no defined sign, so tables or queries that are not
+    // finite never get here: the launcher sends them to the fp64 sweep.)
+    float thm1[MT][4], thm2[MT][4], marw = 0.f, thw = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int64_t qi = qblock + qw + mt * 16 + 4 * quad + r;
+            const float t1 = thr_s[qi], t2 = TWO ? thr2_s[qi] : 0.f;
+            marw = fmaxf(marw, ev.qmar[qi]);
+            if (t1 > -INFINITY) thw = fmaxf(thw, fabsf(t1));
+            if (TWO && t2 > -INFINITY) thw = fmaxf(thw, fabsf(t2));
+            thm1[mt][r] = t1; thm2[mt][r] = t2;
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { marw = fmaxf(marw, __shfl_xor(marw, o, 64)); thw = fmaxf(thw, __shfl_xor(thw, o, 64)); }
+    const float mar_w = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(marw)));
+    const float th_w = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(thw)));
+    const unsigned window = __float_as_uint((2.f * mar_w + 1.2e-7f * (th_w + mar_w)) * 1.000001f);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) { thm1[mt][r] -= mar_w; if (TWO) thm2[mt][r] -= mar_w; }
+
+    half8_t ah[MT][NCH], al[MT][NCH];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+            const int64_t at = (qblock + qw + mt * 16 + col) * KQ + ch * 32 + 8 * quad;
+            ah[mt][ch] = *reinterpret_cast<const half8_t*>(Qh + at);
+            al[mt][ch] = *reinterpret_cast<const half8_t*>(Ql + at);
+        }
+
+    unsigned bits1[MT][4], bits2[MT][4];
+    int nbits = 0;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) { bits1[mt][r] = 0; bits2[mt][r] = 0; }
+    // every (query, column lane) slot of cnt_lds belongs to one lane
+    auto add_up = [&](unsigned mask) {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int q = qw + mt * 16 + 4 * quad + r;
+                cnt_lds[q * 16 + col] += __popc(bits1[mt][r] & mask);
+                if (TWO) cnt_lds[(QB + q) * 16 + col] += __popc(bits2[mt][r] & mask);
+            }
+    };
+
+    // a tile is one contiguous run of each plane (rows are dense, the planes are padded to whole tiles)
+    auto fetch = [&](int item0, half8_t (&ph)[PER], half8_t (&pl)[PER], float& preb) {
+#pragma unroll
+        for (int p = 0; p < PER; p++) {
+            const int64_t at = (int64_t)item0 * KQ + 8 * (int64_t)(tid + 256 * p);
+            ph[p] = *reinterpret_cast<const half8_t*>(Th + at);
+            pl[p] = *reinterpret_cast<const half8_t*>(Tl + at);
+        }
+        preb = tid < NI ? bs[item0 + tid] : 0.f;
+    };
+
+    const int i_begin = (int)blockIdx.y * ev.range_items;
+    const int i_end = (int)min((int64_t)I, (int64_t)i_begin + ev.range_items);
+    const bool shared_lists = ev.ranges > 1;
+    half8_t ph[PER], pl[PER]; float preb;
+    fetch(i_begin, ph, pl, preb);
+    for (int item0 = i_begin; item0 < i_end; item0 += NI) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < PER; p++) {
+            const int e = 8 * (tid + 256 * p), it = e / KQ, k = e % KQ;
+            *reinterpret_cast<half8_t*>(&tile_h[it * STR + k]) = ph[p];
+            *reinterpret_cast<half8_t*>(&tile_l[it * STR + k]) = pl[p];
+        }
+        if (tid < NI) tile_b[tid] = preb;
+        __syncthreads();
+        if (item0 + NI < i_end) fetch(item0 + NI, ph, pl, preb);
+#pragma unroll 1
+        for (int sub = 0; sub < NI / 16; sub++) {
+            const int jj = sub * 16 + col;
+            const int j = item0 + jj;
+            half8_t bh[NCH], bl[NCH];
+#pragma unroll
+            for (int ch = 0; ch < NCH; ch++) {
+                bh[ch] = *reinterpret_cast<const half8_t*>(&tile_h[jj * STR + ch * 32 + 8 * quad]);
+                bl[ch] = *reinterpret_cast<const half8_t*>(&tile_l[jj * STR + ch * 32 + 8 * quad]);
+            }
+            const float bj = tile_b[jj];
+            unsigned mn = 0xffffffffu;
+            float4_t sc[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                float4_t am = (float4_t){bj, bj, bj, bj}, ax = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ch = 0; ch < NCH; ch++) {
+                    am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt][ch], bh[ch], am, 0, 0, 0);
+                    ax = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt][ch], bl[ch], ax, 0, 0, 0);
+                    ax = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt][ch], bh[ch], ax, 0, 0, 0);
+                }
+                sc[mt] = am + ax;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const unsigned y1 = __float_as_uint(sc[mt][r] - thm1[mt][r]);
+                    bits1[mt][r] = __builtin_amdgcn_alignbit(bits1[mt][r], y1, 31);
+                    if (TWO) {
+                        const unsigned y2 = __float_as_uint(sc[mt][r] - thm2[mt][r]);
+                        bits2[mt][r] = __builtin_amdgcn_alignbit(bits2[mt][r], y2, 31);
+                        mn = min(mn, min(y1, y2));
+                    } else {
+                        mn = min(mn, y1);
+                    }
+                }
+            }
+            if (++nbits == 32) { nbits = 0; add_up(~0u); }
+            if (!__ballot(mn <= window)) continue;
+            // some score of the wavefront lies within the margin of a threshold: which ones
+            unsigned open1 = 0, open2 = 0;   // bit (4 mt + r)
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    open1 |= (unsigned)(__float_as_uint(sc[mt][r] - thm1[mt][r]) <= window) << (4 * mt + r);
+                    if (TWO) open2 |= (unsigned)(__float_as_uint(sc[mt][r] - thm2[mt][r]) <= window) << (4 * mt + r);
+                }
+            unsigned open = open1 | open2;
+            while (open) {
+                const int e = __ffs(open) - 1;
+                open &= open - 1;
+                const int qi = qw + (e >> 2) * 16 + 4 * quad + (e & 3);
+                const int which = (int)((open1 >> e) & 1u) | ((int)((open2 >> e) & 1u) << 1);
+                int at;
+                if (shared_lists) {
+                    at = atomicAdd(&ev.amb_cnt[qblock + qi], 1);
+                    if (at >= ev.amb_cap) *ev.amb_overflow = 1;
+                } else {
+                    at = atomicAdd(&q_amb[qi], 1);
+                }
+                if (at < ev.amb_cap) ev.amb[(qblock + qi) * (int64_t)ev.amb_cap + at] = j | (which << 28);
+            }
+        }
+    }
+    __syncthreads();
+    if (!shared_lists)
+        for (int i = tid; i < QB; i += 256) {
+            ev.amb_cnt[qblock + i] = q_amb[i];
+            if (q_amb[i] > ev.amb_cap) *ev.amb_overflow = 1;
+        }
+    if (nbits) add_up(~0u >> (32 - nbits));   // the sub-steps since the last addition
+    __syncthreads();
+    for (int i = tid; i < (TWO ? 2 : 1) * QB; i += 256) {
+        int c = 0;
+#pragma unroll
+        for (int x = 0; x < 16; x++) c += cnt_lds[i * 16 + ((x + i) & 15)];
+        int32_t* dst = (i < QB ? ev.cnt : ev.cnt2) + qblock + (i < QB ? i : i - QB);
+        if (shared_lists) atomicAdd(dst, c); else *dst = c;
+    }
+}
+
 // max_j ||T_j||_2 and max_j |b_j| (as the bit patterns of non-negative floats, which order like unsigned integers).  A
 // wavefront walks items wave, wave + waves, ... and publishes its two maxima once (one atomic per item on the same two
 // words serializes: 4.5 ms for 200k items)
@@ -974,7 +1297,7 @@ static int g_screen_ranges = 0;         // ranges the screen cuts the catalog in
 void eval_configure_ranges(int ranges) { g_screen_ranges = ranges; }
 static int g_screen_mode = 0;           // how the last full-catalog sweep ran: 0 fp64, 1 f32 screen, 2 screen overflowed and fp64 took over
 static int64_t g_screen_open = 0;       // columns the last screen left to fp64, over all queries
-void eval_configure_screen(int on, int cap) { if (on >= 0) g_screen_on = on; if (cap >= 0) g_screen_cap = cap; }
+void eval_configure_screen(int on, int cap) { if (on >= 0) g_screen_on = on; if (cap >= 0) g_screen_cap = cap; }   // on: 0 fp64 sweep, 1 f16 screen, 2 f32 screen
 void eval_screen_stats(int* mode, int64_t* open) { *mode = g_screen_mode; *open = g_screen_open; }
 
 static int screen_qblock(int KQ) { return KQ <= 16 ? 256 : KQ <= 128 ? 128 : 64; }
@@ -994,6 +1317,25 @@ static int launch_screen(const EvalDev& ev, const float* s0, const float* s1, in
     default: rec_set_error("unsupported query width"); return -1;
     }
 #undef SCREEN_CASE
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <bool TWO>
+static int launch_screen16(const EvalDev& ev, int KQ16, const half_t* Th, const half_t* Tl, const float* bs, const half_t* Qh, const half_t* Ql,
+                           const float* thr_s, const float* thr2_s, int n_cols, hipStream_t st)
+{
+#define SCREEN16_CASE(KQv)                                                                                      \
+    case KQv: {                                                                                                 \
+        const unsigned blocks = (unsigned)(ev.nq_pad / Screen16Shape<KQv>::QB);                                 \
+        hipLaunchKernelGGL((score_screen16_kernel<KQv, TWO>), dim3(blocks, ev.ranges), dim3(256), 0, st, ev, Th, Tl, bs, Qh, Ql, thr_s, thr2_s, n_cols); \
+        break;                                                                                                  \
+    }
+    switch (KQ16) {
+        SCREEN16_CASE(32) SCREEN16_CASE(64) SCREEN16_CASE(128) SCREEN16_CASE(256)
+    default: rec_set_error("unsupported query width"); return -1;
+    }
+#undef SCREEN16_CASE
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1030,7 +1372,9 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
     constexpr int L1_QT = 32;
     // f32 tables, the whole catalog, a contraction: the f32 screen decides what it can prove, fp64 the rest
     const bool screen = g_screen_on && sizeof(T) == 4 && !l1 && n_subset <= 0 && kw > 0 && I < (1 << 28);
-    const int qblock = l1 ? L1_QT : screen ? std::max(4 * mt * 16, screen_qblock(ev.KQ)) : 4 * mt * 16;
+    const bool screen16 = screen && g_screen_on == 1;    // 1: the f16 screen (default); 2: the f32 screen
+    const int KQ16 = std::max(32, ev.KQ);
+    const int qblock = l1 ? L1_QT : screen16 ? 256 : screen ? std::max(4 * mt * 16, screen_qblock(ev.KQ)) : 4 * mt * 16;
     ev.nq = m.n_eval * ev.nctx;
     ev.nq_pad = ((ev.nq + qblock - 1) / qblock) * qblock;
 
@@ -1138,7 +1482,7 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
         // rounds of blocks; a query's blocks add their counts and share its list through integer atomics.
         {
             int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            const int64_t resident = (int64_t)cus * 3, blocks = ev.nq_pad / qblock;
+            const int64_t resident = (int64_t)cus * (screen16 ? 2 : 3), blocks = ev.nq_pad / (screen16 ? (KQ16 <= 64 ? 256 : KQ16 <= 128 ? 128 : 64) : qblock);
             const int tile = 128;                                       // a multiple of every tile shape's item count
             int ranges = g_screen_ranges > 0 ? std::min(g_screen_ranges, (I + tile - 1) / tile)
                                              : (int)std::min<int64_t>(std::min<int64_t>(16, (8 * resident + blocks - 1) / blocks), (I + 4095) / 4096);   // at least 4096 items per range
@@ -1157,6 +1501,28 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
     int rc = 0;
     if (l1) {
         rc = launch_score_l1<T, false>(ev, seg0_cols, qtest, qval, NC, m.K, st);
+    } else if (screen16) {
+        // operands as pairs of f16 halves under two power-of-two scales, margins, sweep on the 16-bit matrix pipe
+        const int NI16 = KQ16 <= 128 ? 64 : 32;
+        const int I_pad = ((I + NI16 - 1) / NI16) * NI16;
+        half_t *Th = nullptr, *Tl = nullptr, *Qh = nullptr, *Ql = nullptr; float *bs = nullptr, *thr_s = nullptr, *thr2_s = nullptr; unsigned* b4 = nullptr;
+        EV_TRY(alloc((void**)&Th, sizeof(half_t) * (size_t)I_pad * KQ16));
+        EV_TRY(alloc((void**)&Tl, sizeof(half_t) * (size_t)I_pad * KQ16));
+        EV_TRY(alloc((void**)&bs, sizeof(float) * (size_t)I_pad));
+        EV_TRY(alloc((void**)&Qh, sizeof(half_t) * (size_t)ev.nq_pad * KQ16));
+        EV_TRY(alloc((void**)&Ql, sizeof(half_t) * (size_t)ev.nq_pad * KQ16));
+        EV_TRY(alloc((void**)&thr_s, sizeof(float) * ev.nq_pad));
+        EV_TRY(alloc((void**)&thr2_s, sizeof(float) * ev.nq_pad));
+        EV_TRY(alloc((void**)&b4, sizeof(unsigned) * 4));
+        EV_TRY(hipMemsetAsync(b4, 0, sizeof(unsigned) * 4, st));
+        hipLaunchKernelGGL(screen16_bounds_kernel, dim3(1024), dim3(256), 0, st, ev, (const float*)seg0_cols, (const float*)seg1_cols, I, b4);
+        hipLaunchKernelGGL(screen16_items_kernel, dim3(2048), dim3(256), 0, st, ev, (const float*)seg0_cols, (const float*)seg1_cols, I, I_pad, KQ16,
+                           (const unsigned*)b4, Th, Tl, bs, ev.amb_overflow);
+        hipLaunchKernelGGL(screen16_queries_kernel, dim3(blocks_for_waves(ev.nq_pad)), dim3(256), 0, st, ev, KQ16, (const unsigned*)b4, Qh, Ql, thr_s, thr2_s,
+                           ev.amb_overflow);
+        ev.heldout_counted = 1;
+        rc = ev.nctx == 1 ? launch_screen16<true>(ev, KQ16, Th, Tl, bs, Qh, Ql, thr_s, thr2_s, NC, st)
+                          : launch_screen16<false>(ev, KQ16, Th, Tl, bs, Qh, Ql, thr_s, thr2_s, NC, st);
     } else if (screen) {
         hipLaunchKernelGGL(screen_item_bounds_kernel, dim3(std::min(1024u, blocks_for_waves(I))), dim3(256), 0, st, ev, (const float*)seg0_cols, (const float*)seg1_cols, I, bounds);
         ev.heldout_counted = 1;
