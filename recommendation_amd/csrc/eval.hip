@@ -898,17 +898,22 @@ __global__ void __launch_bounds__(256, 2) score_screen16_kernel(EvalDev ev, cons
         if (tid < NI) tile_b[tid] = preb;
         __syncthreads();
         if (item0 + NI < i_end) fetch(item0 + NI, ph, pl, preb);
-#pragma unroll 1
-        for (int sub = 0; sub < NI / 16; sub++) {
+        // the item fragments of a sub-step are read from LDS while the epilogue of the sub-step before it runs (into the
+        // registers its MFMAs have just finished with): a wait for them at the top of every sub-step was 40 % of the kernel
+        half8_t bh[NCH], bl[NCH]; float bj;
+        auto read_frags = [&](int sub) {
             const int jj = sub * 16 + col;
-            const int j = item0 + jj;
-            half8_t bh[NCH], bl[NCH];
 #pragma unroll
             for (int ch = 0; ch < NCH; ch++) {
                 bh[ch] = *reinterpret_cast<const half8_t*>(&tile_h[jj * STR + ch * 32 + 8 * quad]);
                 bl[ch] = *reinterpret_cast<const half8_t*>(&tile_l[jj * STR + ch * 32 + 8 * quad]);
             }
-            const float bj = tile_b[jj];
+            bj = tile_b[jj];
+        };
+        read_frags(0);
+#pragma unroll 1
+        for (int sub = 0; sub < NI / 16; sub++) {
+            const int j = item0 + sub * 16 + col;
             unsigned mn = 0xffffffffu;
             float4_t sc[MT];
 #pragma unroll
@@ -921,6 +926,10 @@ __global__ void __launch_bounds__(256, 2) score_screen16_kernel(EvalDev ev, cons
                     ax = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt][ch], bh[ch], ax, 0, 0, 0);
                 }
                 sc[mt] = am + ax;
+            }
+            if (sub + 1 < NI / 16) read_frags(sub + 1);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const unsigned y1 = __float_as_uint(sc[mt][r] - thm1[mt][r]);

@@ -19,12 +19,16 @@ def main():
     ap.add_argument("--k", type=int, default=64)
     ap.add_argument("--model", default="BPRMF")
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--ranges", type=int, default=0, help="eval_ranges: ranges the screen cuts the catalog into (0 = automatic)")
+    ap.add_argument("--screen", type=int, default=1, help="eval_screen: 0 fp64 sweep, 1 f16 screen, 2 f32 screen")
     args = ap.parse_args()
     import torch
     seq_off, seq_item, test, val, _ = make_synthetic(args.users, args.items, args.clicks, 7, torch.device("cuda:0"))
     eng = ra.Engine(args.model, args.items, seq_off, seq_item, test, val, K=args.k, lam=0.01, bias_reg=0.01, alpha=0.5, precision=F32)
     eng.init_params(seed=1)
     eng.set_option("profile", 1)
+    eng.set_option("eval_ranges", args.ranges)
+    eng.set_option("eval_screen", args.screen)
     for _ in range(args.reps):
         t0 = time.perf_counter()
         eng.eval_sums(50)
