@@ -675,11 +675,15 @@ __global__ void __launch_bounds__(256, DENSE && KQ <= 64 ? 3 : 2) score_screen_k
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 half_t;
 
-template <int KQ> struct Screen16Shape {
-    static constexpr int MT = KQ <= 64 ? 4 : KQ <= 128 ? 2 : 1;   // 16-query tiles per wavefront
+template <int KQ, bool TWO> struct Screen16Shape {
+    // 16-query tiles per wavefront.  Measured at 1M users x 200k items, K = 64: with two thresholds per query (BPRMF) two
+    // tiles at three wavefronts per SIMD run 85 ms against 90 ms for four tiles at two; with one threshold it is 139 against 133
+    static constexpr int MT = KQ <= 64 ? (TWO ? 2 : 4) : KQ <= 128 ? 2 : 1;
+    static constexpr int WAVES = (KQ <= 64 && TWO) ? 3 : 2;       // wavefronts per SIMD the registers are held to
     static constexpr int NI = KQ <= 128 ? 64 : 32;                // items per tile
     static constexpr int QB = 4 * MT * 16;                        // queries per block
 };
+static int screen16_qb(int KQ16, bool two) { return KQ16 <= 64 ? (two ? 128 : 256) : KQ16 <= 128 ? 128 : 64; }
 
 // power-of-two scale that puts a largest magnitude m into [2^13, 2^14); 1 when m is 0, infinite or NaN
 __device__ __forceinline__ double screen16_scale(unsigned max_bits)
@@ -789,11 +793,11 @@ __global__ void __launch_bounds__(256) screen16_queries_kernel(EvalDev ev, int K
 }
 
 template <int KQ, bool TWO>
-__global__ void __launch_bounds__(256, 2) score_screen16_kernel(EvalDev ev, const half_t* __restrict__ Th, const half_t* __restrict__ Tl, const float* __restrict__ bs,
+__global__ void __launch_bounds__(256, (Screen16Shape<KQ, TWO>::WAVES)) score_screen16_kernel(EvalDev ev, const half_t* __restrict__ Th, const half_t* __restrict__ Tl, const float* __restrict__ bs,
                                                                 const half_t* __restrict__ Qh, const half_t* __restrict__ Ql, const float* __restrict__ thr_s,
                                                                 const float* __restrict__ thr2_s, int I)
 {
-    constexpr int MT = Screen16Shape<KQ>::MT, NI = Screen16Shape<KQ>::NI, QB = Screen16Shape<KQ>::QB;
+    constexpr int MT = Screen16Shape<KQ, TWO>::MT, NI = Screen16Shape<KQ, TWO>::NI, QB = Screen16Shape<KQ, TWO>::QB;
     constexpr int NCH = KQ / 32;              // MFMA steps of 32 contraction indices
     constexpr int STR = KQ + 8;               // halfs per tile row: KQ / 2 + 4 dwords, conflict-free 16-byte reads by 16 lanes
     constexpr int PER = NI * KQ / 8 / 256;    // 16-byte pieces of a plane's tile per thread
@@ -910,6 +914,8 @@ __global__ void __launch_bounds__(256, 2) score_screen16_kernel(EvalDev ev, cons
             }
             bj = tile_b[jj];
         };
+        // (Writing the MFMAs of sub-step s + 1 next to the epilogue of sub-step s, so that the scheduler could interleave
+        // them, was measured and changed nothing: 133.0 against 132.6 ms for 2M queries.)
         read_frags(0);
 #pragma unroll 1
         for (int sub = 0; sub < NI / 16; sub++) {
@@ -944,7 +950,7 @@ __global__ void __launch_bounds__(256, 2) score_screen16_kernel(EvalDev ev, cons
                 }
             }
             if (++nbits == 32) { nbits = 0; add_up(~0u); }
-            if (!__ballot(mn <= window)) continue;
+            if (__ballot(mn <= window)) {
             // some score of the wavefront lies within the margin of a threshold: which ones
             unsigned open1 = 0, open2 = 0;   // bit (4 mt + r)
 #pragma unroll
@@ -968,6 +974,7 @@ __global__ void __launch_bounds__(256, 2) score_screen16_kernel(EvalDev ev, cons
                     at = atomicAdd(&q_amb[qi], 1);
                 }
                 if (at < ev.amb_cap) ev.amb[(qblock + qi) * (int64_t)ev.amb_cap + at] = j | (which << 28);
+            }
             }
         }
     }
@@ -1336,7 +1343,7 @@ static int launch_screen16(const EvalDev& ev, int KQ16, const half_t* Th, const 
 {
 #define SCREEN16_CASE(KQv)                                                                                      \
     case KQv: {                                                                                                 \
-        const unsigned blocks = (unsigned)(ev.nq_pad / Screen16Shape<KQv>::QB);                                 \
+        const unsigned blocks = (unsigned)(ev.nq_pad / Screen16Shape<KQv, TWO>::QB);                            \
         hipLaunchKernelGGL((score_screen16_kernel<KQv, TWO>), dim3(blocks, ev.ranges), dim3(256), 0, st, ev, Th, Tl, bs, Qh, Ql, thr_s, thr2_s, n_cols); \
         break;                                                                                                  \
     }
@@ -1491,7 +1498,7 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
         // rounds of blocks; a query's blocks add their counts and share its list through integer atomics.
         {
             int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            const int64_t resident = (int64_t)cus * (screen16 ? 2 : 3), blocks = ev.nq_pad / (screen16 ? (KQ16 <= 64 ? 256 : KQ16 <= 128 ? 128 : 64) : qblock);
+            const int64_t resident = (int64_t)cus * ((screen16 && !(KQ16 <= 64 && ev.nctx == 1)) ? 2 : 3), blocks = ev.nq_pad / (screen16 ? screen16_qb(KQ16, ev.nctx == 1) : qblock);
             const int tile = 128;                                       // a multiple of every tile shape's item count
             int ranges = g_screen_ranges > 0 ? std::min(g_screen_ranges, (I + tile - 1) / tile)
                                              : (int)std::min<int64_t>(std::min<int64_t>(16, (8 * resident + blocks - 1) / blocks), (I + 4095) / 4096);   // at least 4096 items per range
