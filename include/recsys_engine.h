@@ -264,14 +264,16 @@ int rec_project_rows(rec_engine* e);
  *   "stale_window"  tuples per update launch for small catalogs (0 = no limit)
  *   "global_window" tuples per update launch for models with a row every tuple touches
  *   "global_cap"    such a row moves by at most this many steps' worth of learning rate per launch
- *   "eval_screen"   1 (default): with f32 tables the full-catalog sweep of rec_eval runs on the FP32 matrix pipe and decides
- *                   every comparison it can prove from a rounding bound; the columns within the bound of a threshold are
- *                   decided in fp64, so the counts are those of the fp64 sweep.  0: fp64 sweep.  (process-wide)
- *   "eval_screen_cap"  columns per query the screen may leave to fp64 (default 0 = max(64, n_items / 2048)); a query that
- *                   needs more makes the whole sweep run again in fp64
+ *   "eval_screen"   with f32 tables the full-catalog sweep of rec_eval runs on a matrix pipe narrower than fp64 and decides every
+ *                   comparison it can prove from a rounding bound; the columns within the bound of a threshold are decided in
+ *                   fp64, so the counts are those of the fp64 sweep.  1 (default): the 16-bit pipe, every operand as two f16
+ *                   halves under power-of-two scales (three MFMAs per 32 contraction indices); 2: the FP32 matrix pipe; 0: the
+ *                   fp64 sweep.  Tables or queries that are not finite always take the fp64 sweep.  (process-wide)
+ *   "eval_screen_cap"  columns per query the screen may leave to fp64 (default 0 = max(64, n_items / 1024), f32 screen: / 2048); a
+ *                   query that needs more makes the whole sweep run again in fp64
  *   "project_after_launch"  TransRec: 1 (default) = every update launch ends with the projection of all item rows onto the unit
  *                   ball; 0 = the caller does it (rec_project_rows), see there
- *   "eval_ranges"   ranges the f32 screen cuts the catalog into, each swept by its own blocks (0, the default: one range
+ *   "eval_ranges"   ranges the screen cuts the catalog into, each swept by its own blocks (0, the default: one range
  *                   unless the query blocks alone would not fill the chip evenly - few users per engine; then up to 16).  The
  *                   counts do not depend on it.  (process-wide)
  *   "profile"       time every update / scoring / sampler launch with HIP events */

@@ -1484,7 +1484,7 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
     if (screen) {
         // undecided columns per query grow with the catalog (margin x columns per unit of score): room for I / 2048 of them,
         // at least 64, unless the caller has fixed it
-        ev.amb_cap = g_screen_cap > 0 ? g_screen_cap : std::max(64, ((I / 2048 + 31) / 32) * 32);
+        ev.amb_cap = g_screen_cap > 0 ? g_screen_cap : std::max(64, ((I / (screen16 ? 1024 : 2048) + 31) / 32) * 32);   // the f16 screen's margin is the wider one
         EV_TRY(alloc((void**)&ev.qmar, sizeof(float) * ev.nq_pad));
         EV_TRY(alloc((void**)&ev.amb, sizeof(int32_t) * (size_t)ev.nq_pad * ev.amb_cap));
         EV_TRY(alloc((void**)&ev.amb_cnt, sizeof(int32_t) * ev.nq_pad));

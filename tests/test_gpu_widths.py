@@ -127,7 +127,8 @@ def test_f32_screen_gives_the_counts_of_the_fp64_sweep(model, K):
     # ("eval_ranges": the catalog cut into that many ranges, each swept by blocks of its own that share a query's counts and
     # list; 0 = chosen from the number of query blocks - two ranges here)
     for name, opts in (("fp64", {"eval_screen": 0}), ("screen", {"eval_screen": 1, "eval_screen_cap": 1024}),
-                       ("one_range", {"eval_ranges": 1}), ("seven_ranges", {"eval_ranges": 7}), ("overflow", {"eval_screen_cap": 1, "eval_ranges": 0})):
+                       ("one_range", {"eval_ranges": 1}), ("seven_ranges", {"eval_ranges": 7}),
+                       ("f32_screen", {"eval_screen": 2, "eval_ranges": 0}), ("overflow", {"eval_screen": 1, "eval_screen_cap": 1})):
         for k, v in opts.items():
             e.set_option(k, v)
         _, counts, _ = e.eval()
@@ -142,8 +143,21 @@ def test_f32_screen_gives_the_counts_of_the_fp64_sweep(model, K):
     for name in ("one_range", "seven_ranges"):
         assert got[name][1] == 1 and got[name][2] == got["screen"][2], (name, got[name][1:], got["screen"][1:])
         assert np.array_equal(got[name][0], got["fp64"][0]), name
+    # the FP32-pipe screen ("eval_screen" 2; the default is the f16 one) proves a little more by itself
+    assert got["f32_screen"][1] == 1 and 0 < got["f32_screen"][2] <= got["screen"][2]
+    assert np.array_equal(got["f32_screen"][0], got["fp64"][0])
     assert np.array_equal(got["overflow"][0], got["fp64"][0])
     o = orc.Oracle(model, U, I, K, seq_off, seq_item, test, val, path_off=po, path_item=pi, **{k: v for k, v in kw.items() if k != "K"})
     _, ref = o.eval(W)
     assert np.array_equal(got["screen"][0], ref)
+    # tables that are not finite (a diverged model): both screens hand the sweep to fp64, whose comparisons with NaN are all false
+    Wn = W.copy()
+    Wn[len(Wn) - 3] = np.nan; Wn[len(Wn) - 2 * K - 1] = np.inf
+    e.upload(Wn)
+    e.set_option("eval_screen", 0)
+    want = e.eval()[1].copy()
+    for mode in (1, 2):
+        e.set_option("eval_screen", mode)
+        assert np.array_equal(e.eval()[1], want), mode
+    e.set_option("eval_screen", 1)
     e.close()
