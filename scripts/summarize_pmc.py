@@ -17,7 +17,7 @@ for d in dirs:
     for f in glob.glob(d + "/*/*_counter_collection.csv") + glob.glob(d + "/*_counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
-            if any(k in name for k in ("sgd_", "sampler_kernel", "score_count", "score_screen", "correct_clicked", "build_queries", "part_")):
+            if any(k in name for k in ("sgd_", "sampler_kernel", "score_count", "score_screen", "screen16_", "correct_clicked", "build_queries", "part_")):
                 agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for k, v in agg.items():
@@ -27,7 +27,7 @@ for k, v in agg.items():
         e["fetch_bytes"] = e["FETCH_SIZE"] * 1024
     if "WRITE_SIZE" in e:
         e["write_bytes"] = e["WRITE_SIZE"] * 1024
-    wide = "sgd_wide_kernel" in k or "score_screen_kernel" in k
+    wide = "sgd_wide_kernel" in k or "score_screen_kernel" in k or "score_screen16_kernel" in k
     if "fetch_bytes" in e and wide:
         e["fetch_bytes_corrected"] = 2 * e["fetch_bytes"]
     if "fetch_bytes" in e and "write_bytes" in e:
