@@ -269,8 +269,8 @@ int rec_project_rows(rec_engine* e);
  *                   fp64, so the counts are those of the fp64 sweep.  1 (default): the 16-bit pipe, every operand as two f16
  *                   halves under power-of-two scales (three MFMAs per 32 contraction indices); 2: the FP32 matrix pipe; 0: the
  *                   fp64 sweep.  Tables or queries that are not finite always take the fp64 sweep.  (process-wide)
- *   "eval_screen_cap"  columns per query the screen may leave to fp64 (default 0 = max(64, n_items / 1024), f32 screen: / 2048); a
- *                   query that needs more makes the whole sweep run again in fp64
+ *   "eval_screen_cap"  columns per query the screen may leave to fp64 (default 0 = n_items / 128 within 256 .. 4096, f32 screen:
+ *                   max(64, n_items / 2048)); a query that needs more makes the whole sweep run again in fp64
  *   "project_after_launch"  TransRec: 1 (default) = every update launch ends with the projection of all item rows onto the unit
  *                   ball; 0 = the caller does it (rec_project_rows), see there
  *   "eval_ranges"   ranges the screen cuts the catalog into, each swept by its own blocks (0, the default: one range

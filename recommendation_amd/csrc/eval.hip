@@ -665,8 +665,8 @@ __global__ void __launch_bounds__(256, DENSE && KQ <= 64 ? 3 : 2) score_screen_k
 // is an absolute one).  Products of two f16 numbers are exact in f32, so
 //     <q, T> = sum (qh Th)  +  sum (qh Tl + ql Th)  +  [ ql Tl + eq T + q eT ]
 //              main chain      cross chain (2^-11 of the main one)     dropped: <= 3.3 * 2^-22 ||q|| ||T|| + the 2^-25 floors
-// is three MFMAs per 32 contraction indices.  The two chains have accumulators of their own: the main one (KQ products
-// on top of b_j) carries the accumulation error, (KQ + 3) roundings of relative size 2^-23 at most (twice the unit
+// is three MFMAs per 32 contraction indices.  The two chains have accumulators of their own: the main one (KQ products;
+// b_j is added to the sum of the two chains afterwards) carries the accumulation error, (KQ + 3) roundings of relative size 2^-23 at most (twice the unit
 // roundoff: the bound holds whether the matrix pipe rounds to nearest or truncates, and for any order of summation);
 // the cross chain's terms are 2^-11 of that.  The margin of a query (screen16_queries_kernel) adds these up; a column
 // whose score is further than the margin from the threshold is decided for certain, the others go to the fp64 recheck
@@ -780,8 +780,8 @@ __global__ void __launch_bounds__(256) screen16_queries_kernel(EvalDev ev, int K
         const double ta = (isfinite(t1) ? fabs(t1) : 0.0) + (isfinite(t2) ? fabs(t2) : 0.0);
         const double rep = 3.3 * 4.0 * u * s * tmax;                                              // 3.3 * 2^-22: halves dropped or rounded away
         const double sub = 6.103515625e-05 * sqrt((double)KQ16) * (tmax / sq + s / sT);          // 2^-14 per element: holds even if the matrix pipe flushed f16 subnormals (rounding alone: 2^-25)
-        const double acc = 2.0 * (KQ16 + 3) * u * (bmax + 1.002 * s * tmax) + KQ16 * (u / 64.0) * s * tmax;   // main chain; cross chain
-        const double rnd = 4.0 * u * (bmax + ta + s * tmax);                                      // thresholds and constants rounded to f32, the subtraction
+        const double acc = 2.0 * (KQ16 + 3) * u * 1.002 * s * tmax + KQ16 * (u / 64.0) * s * tmax;  // main chain; cross chain
+        const double rnd = 4.0 * u * (bmax + ta + s * tmax);                                      // thresholds and constants rounded to f32, the two final additions, the subtraction
         const double mq = 1.05 * (rep + sub + acc + rnd) + 1e-30;
         ev.qmar[w] = w < ev.nq ? __double2float_ru(mq * S * 1.000001) : 0.f;                       // a padding row decides nothing and lists nothing
         thr_s[w] = (float)(t1 * S);
@@ -924,14 +924,17 @@ __global__ void __launch_bounds__(256, (Screen16Shape<KQ, TWO>::WAVES)) score_sc
             float4_t sc[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
-                float4_t am = (float4_t){bj, bj, bj, bj}, ax = (float4_t){0.f, 0.f, 0.f, 0.f};
+                // b_j is added after the chains: as their starting value it would make every one of their roundings relative
+                // to |b_j|, and where the constants dominate the scores (Fossil's tables start at 1e-6) the margin then
+                // covered hundreds of columns per query
+                float4_t am = (float4_t){0.f, 0.f, 0.f, 0.f}, ax = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ch = 0; ch < NCH; ch++) {
                     am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt][ch], bh[ch], am, 0, 0, 0);
                     ax = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt][ch], bl[ch], ax, 0, 0, 0);
                     ax = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt][ch], bh[ch], ax, 0, 0, 0);
                 }
-                sc[mt] = am + ax;
+                sc[mt] = (am + ax) + bj;
             }
             if (sub + 1 < NI / 16) read_frags(sub + 1);
 #pragma unroll
@@ -1484,7 +1487,18 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
     if (screen) {
         // undecided columns per query grow with the catalog (margin x columns per unit of score): room for I / 2048 of them,
         // at least 64, unless the caller has fixed it
-        ev.amb_cap = g_screen_cap > 0 ? g_screen_cap : std::max(64, ((I / (screen16 ? 1024 : 2048) + 31) / 32) * 32);   // the f16 screen's margin is the wider one
+        // The f16 screen's margin is the wider one, and the margin of a query grows with its norm: at the 1M x 200k shape a
+        // trained Fossil model leaves 17 columns per query on average and more than 224 for a few users with histories of
+        // thousands of clicks - which sent the WHOLE sweep to fp64 (1.08 s instead of 0.2).  The lists are virtual space
+        // until written, so they are sized generously: I / 128 columns (256 .. 4096), within 32 GB for all queries.
+        if (screen16) {
+            int64_t cap = std::min<int64_t>(4096, std::max<int64_t>(256, ((I / 128 + 31) / 32) * 32));
+            const int64_t room = ((int64_t)32 << 30) / ((int64_t)ev.nq_pad * 4);
+            if (cap > room) cap = std::max<int64_t>(64, room / 32 * 32);
+            ev.amb_cap = g_screen_cap > 0 ? g_screen_cap : (int)cap;
+        } else {
+            ev.amb_cap = g_screen_cap > 0 ? g_screen_cap : std::max(64, ((I / 2048 + 31) / 32) * 32);
+        }
         EV_TRY(alloc((void**)&ev.qmar, sizeof(float) * ev.nq_pad));
         EV_TRY(alloc((void**)&ev.amb, sizeof(int32_t) * (size_t)ev.nq_pad * ev.amb_cap));
         EV_TRY(alloc((void**)&ev.amb_cnt, sizeof(int32_t) * ev.nq_pad));
