@@ -281,8 +281,9 @@ int rec_set_option(rec_engine* e, const char* name, int64_t value);
 
 /* HIP-event statistics gathered while "profile" = 1: which = 0 SGD update (in owner mode: the partition and the update
  * kernel together), 1 eval scoring kernel, 2 sampler, 3 the owner mode's partition alone.  Resets the counters.
- * which = 4 (not reset): how the last full-catalog sweep ran - *launches = 0 fp64, 1 f32 screen, 2 screen overflowed and
- * fp64 took over; *total_ms = the number of columns the screen left to fp64, over all queries. */
+ * which = 4 (not reset): how the last full-catalog sweep ran - *launches = 0 fp64, 1 the selected screen held, 2 a query
+ * overflowed its list of undecided columns and fp64 took over, 3 the f16 screen overflowed and the f32 screen, tried next,
+ * held; *total_ms = the number of columns the screen left to fp64, over all queries. */
 int rec_kernel_stats(rec_engine* e, int which, double* total_ms, int64_t* launches);
 
 #ifdef __cplusplus

@@ -1529,6 +1529,15 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (profile) { EV_TRY(hipEventCreate(&e0)); EV_TRY(hipEventCreate(&e1)); EV_TRY(hipEventRecord(e0, st)); }
     int rc = 0;
+    // the sweep on the FP32 matrix pipe ("eval_screen" 2, and the second try when the f16 screen's wider margin has
+    // overflowed a query's list)
+    auto run_f32_screen = [&]() -> int {
+        hipLaunchKernelGGL(screen_item_bounds_kernel, dim3(std::min(1024u, blocks_for_waves(I))), dim3(256), 0, st, ev, (const float*)seg0_cols, (const float*)seg1_cols, I, bounds);
+        ev.heldout_counted = 1;
+        hipLaunchKernelGGL(screen_margins_kernel, dim3(blocks_for_waves(ev.nq_pad)), dim3(256), 0, st, ev, (const unsigned*)bounds);
+        return ev.nctx == 1 ? launch_screen<true>(ev, (const float*)seg0_cols, (const float*)seg1_cols, NC, qtest, qval, st)
+                            : launch_screen<false>(ev, (const float*)seg0_cols, (const float*)seg1_cols, NC, qtest, qval, st);
+    };
     if (l1) {
         rc = launch_score_l1<T, false>(ev, seg0_cols, qtest, qval, NC, m.K, st);
     } else if (screen16) {
@@ -1554,11 +1563,7 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
         rc = ev.nctx == 1 ? launch_screen16<true>(ev, KQ16, Th, Tl, bs, Qh, Ql, thr_s, thr2_s, NC, st)
                           : launch_screen16<false>(ev, KQ16, Th, Tl, bs, Qh, Ql, thr_s, thr2_s, NC, st);
     } else if (screen) {
-        hipLaunchKernelGGL(screen_item_bounds_kernel, dim3(std::min(1024u, blocks_for_waves(I))), dim3(256), 0, st, ev, (const float*)seg0_cols, (const float*)seg1_cols, I, bounds);
-        ev.heldout_counted = 1;
-        hipLaunchKernelGGL(screen_margins_kernel, dim3(blocks_for_waves(ev.nq_pad)), dim3(256), 0, st, ev, (const unsigned*)bounds);
-        rc = ev.nctx == 1 ? launch_screen<true>(ev, (const float*)seg0_cols, (const float*)seg1_cols, NC, qtest, qval, st)
-                          : launch_screen<false>(ev, (const float*)seg0_cols, (const float*)seg1_cols, NC, qtest, qval, st);
+        rc = run_f32_screen();
     } else {
         rc = ev.nctx == 1 ? launch_score<T, true, false>(ev, seg0_cols, seg1_cols, NC, qtest, qval, st)
                           : launch_score<T, false, false>(ev, seg0_cols, seg1_cols, NC, qtest, qval, st);
@@ -1570,7 +1575,24 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
         int32_t over = 0;
         EV_TRY(hipMemcpyAsync(&over, ev.amb_overflow, sizeof over, hipMemcpyDeviceToHost, st));
         EV_TRY(hipStreamSynchronize(st));
-        g_screen_mode = over ? 2 : 1; g_screen_open = 0;
+        bool second_try = false;
+        if (over && screen16) {
+            // the f32 screen's margin is less than half as wide: it may hold where the f16 screen did not, at a quarter of
+            // the fp64 sweep's time
+            second_try = true;
+            EV_TRY(hipMemsetAsync(ev.amb_overflow, 0, sizeof(int32_t), st));
+            EV_TRY(hipMemsetAsync(bounds, 0, sizeof(unsigned) * 2, st));
+            EV_TRY(hipMemsetAsync(ev.amb_cnt, 0, sizeof(int32_t) * ev.nq_pad, st));
+            if (ev.ranges > 1) {
+                EV_TRY(hipMemsetAsync(ev.cnt, 0, sizeof(int32_t) * ev.nq_pad, st));
+                EV_TRY(hipMemsetAsync(ev.cnt2, 0, sizeof(int32_t) * ev.nq_pad, st));
+            }
+            rc = run_f32_screen();
+            if (rc) { release(); return rc; }
+            EV_TRY(hipMemcpyAsync(&over, ev.amb_overflow, sizeof over, hipMemcpyDeviceToHost, st));
+            EV_TRY(hipStreamSynchronize(st));
+        }
+        g_screen_mode = over ? 2 : second_try ? 3 : 1; g_screen_open = 0;
         if (profile) {
             std::vector<int32_t> open(ev.nq);
             EV_TRY(hipMemcpy(open.data(), ev.amb_cnt, sizeof(int32_t) * ev.nq, hipMemcpyDeviceToHost));
