@@ -665,10 +665,14 @@ __global__ void __launch_bounds__(256, DENSE && KQ <= 64 ? 3 : 2) score_screen_k
 // is an absolute one).  Products of two f16 numbers are exact in f32, so
 //     <q, T> = sum (qh Th)  +  sum (qh Tl + ql Th)  +  [ ql Tl + eq T + q eT ]
 //              main chain      cross chain (2^-11 of the main one)     dropped: <= 3.3 * 2^-22 ||q|| ||T|| + the 2^-25 floors
-// is three MFMAs per 32 contraction indices.  The two chains have accumulators of their own: the main one (KQ products;
-// b_j is added to the sum of the two chains afterwards) carries the accumulation error, (KQ + 3) roundings of relative size 2^-23 at most (twice the unit
-// roundoff: the bound holds whether the matrix pipe rounds to nearest or truncates, and for any order of summation);
-// the cross chain's terms are 2^-11 of that.  The margin of a query (screen16_queries_kernel) adds these up; a column
+// is three MFMAs per 32 contraction indices.  One accumulator takes the cross chain FIRST and the main chain after it (b_j
+// is added to the result): a main product then passes through at most KQ + 3 roundings (its own chain, b_j, the
+// subtraction of the threshold) of relative size 2^-23 at most (twice the unit roundoff: the bound holds whether the
+// matrix pipe rounds to nearest or truncates, and for any order of summation inside an instruction), and the cross
+// products, 2^-10 of the main ones together, through at most 3 KQ + 3.  (The other order - cross products added to a full
+// main sum - would round every one of them relative to the main sum.  Two accumulators and an addition, the first form of
+// this kernel, have the same bound and cost a vector instruction per score: 88 -> 83 ms for 1M x 200k.)
+// The margin of a query (screen16_queries_kernel) adds these up; a column
 // whose score is further than the margin from the threshold is decided for certain, the others go to the fp64 recheck
 // exactly as in the f32 screen.  Operand maps: lane l holds A[row l & 15][k = 8 (l >> 4) + j] and B[k = 8 (l >> 4) + j]
 // [col l & 15], j = 0..7; D[row 4 (l >> 4) + r][col l & 15].
@@ -780,7 +784,7 @@ __global__ void __launch_bounds__(256) screen16_queries_kernel(EvalDev ev, int K
         const double ta = (isfinite(t1) ? fabs(t1) : 0.0) + (isfinite(t2) ? fabs(t2) : 0.0);
         const double rep = 3.3 * 4.0 * u * s * tmax;                                              // 3.3 * 2^-22: halves dropped or rounded away
         const double sub = 6.103515625e-05 * sqrt((double)KQ16) * (tmax / sq + s / sT);          // 2^-14 per element: holds even if the matrix pipe flushed f16 subnormals (rounding alone: 2^-25)
-        const double acc = 2.0 * (KQ16 + 3) * u * 1.002 * s * tmax + KQ16 * (u / 64.0) * s * tmax;  // main chain; cross chain
+        const double acc = 2.0 * (KQ16 + 3) * u * 1.002 * s * tmax + KQ16 * (u / 64.0) * s * tmax;  // main products; cross products ((3 KQ + 3) 2 u 2^-10 <= KQ u / 64)
         const double rnd = 4.0 * u * (bmax + ta + s * tmax);                                      // thresholds and constants rounded to f32, the two final additions, the subtraction
         const double mq = 1.05 * (rep + sub + acc + rnd) + 1e-30;
         ev.qmar[w] = w < ev.nq ? __double2float_ru(mq * S * 1.000001) : 0.f;                       // a padding row decides nothing and lists nothing
@@ -921,20 +925,24 @@ __global__ void __launch_bounds__(256, (Screen16Shape<KQ, TWO>::WAVES)) score_sc
         for (int sub = 0; sub < NI / 16; sub++) {
             const int j = item0 + sub * 16 + col;
             unsigned mn = 0xffffffffu;
-            float4_t sc[MT];
+            float sc[MT][4];
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
                 // b_j is added after the chains: as their starting value it would make every one of their roundings relative
                 // to |b_j|, and where the constants dominate the scores (Fossil's tables start at 1e-6) the margin then
                 // covered hundreds of columns per query
-                float4_t am = (float4_t){0.f, 0.f, 0.f, 0.f}, ax = (float4_t){0.f, 0.f, 0.f, 0.f};
+                float4_t am = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ch = 0; ch < NCH; ch++) {
-                    am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt][ch], bh[ch], am, 0, 0, 0);
-                    ax = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt][ch], bl[ch], ax, 0, 0, 0);
-                    ax = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt][ch], bh[ch], ax, 0, 0, 0);
+                    am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt][ch], bl[ch], am, 0, 0, 0);
+                    am = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt][ch], bh[ch], am, 0, 0, 0);
                 }
-                sc[mt] = (am + ax) + bj;
+#pragma unroll
+                for (int ch = 0; ch < NCH; ch++) am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt][ch], bh[ch], am, 0, 0, 0);
+                // element by element, and the file is built without SLP vectorisation: next to MFMAs a v_pk_add_f32 costs
+                // more issue time than the two v_add_f32 it replaces, and this loop is bound by vector issue
+#pragma unroll
+                for (int r = 0; r < 4; r++) sc[mt][r] = am[r] + bj;
             }
             if (sub + 1 < NI / 16) read_frags(sub + 1);
 #pragma unroll
@@ -946,7 +954,7 @@ __global__ void __launch_bounds__(256, (Screen16Shape<KQ, TWO>::WAVES)) score_sc
                     if (TWO) {
                         const unsigned y2 = __float_as_uint(sc[mt][r] - thm2[mt][r]);
                         bits2[mt][r] = __builtin_amdgcn_alignbit(bits2[mt][r], y2, 31);
-                        mn = min(mn, min(y1, y2));
+                        mn = min(min(mn, y1), y2);   // one v_min3_u32
                     } else {
                         mn = min(mn, y1);
                     }

@@ -21,7 +21,10 @@ def main():
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--ranges", type=int, default=0, help="eval_ranges: ranges the screen cuts the catalog into (0 = automatic)")
     ap.add_argument("--screen", type=int, default=1, help="eval_screen: 0 fp64 sweep, 1 f16 screen, 2 f32 screen")
+    ap.add_argument("--lib", default="", help="another build of the library to load (A/B runs of kernel variants)")
     args = ap.parse_args()
+    if args.lib:
+        ra.capi.LIB_PATH = os.path.abspath(args.lib)
     import torch
     seq_off, seq_item, test, val, _ = make_synthetic(args.users, args.items, args.clicks, 7, torch.device("cuda:0"))
     eng = ra.Engine(args.model, args.items, seq_off, seq_item, test, val, K=args.k, lam=0.01, bias_reg=0.01, alpha=0.5, precision=F32)
