@@ -806,8 +806,9 @@ __global__ void __launch_bounds__(256, (Screen16Shape<KQ, TWO>::WAVES)) score_sc
     constexpr int STR = KQ + 8;               // halfs per tile row: KQ / 2 + 4 dwords, conflict-free 16-byte reads by 16 lanes
     constexpr int PER = NI * KQ / 8 / 256;    // 16-byte pieces of a plane's tile per thread
     static_assert(PER >= 1 && KQ % 32 == 0, "tile shape");
-    __shared__ __align__(16) half_t tile_h[NI * STR];
-    __shared__ __align__(16) half_t tile_l[NI * STR];
+    __shared__ __align__(16) half_t tiles[2 * NI * STR];   // the high plane, then the low plane: one address register and immediate offsets reach both
+    half_t* const tile_h = tiles;
+    half_t* const tile_l = tiles + NI * STR;
     __shared__ float tile_b[NI];
     __shared__ int q_amb[QB];
     __shared__ int cnt_lds[(TWO ? 2 : 1) * QB * 16];   // counts so far per (threshold, query, column lane): registers are short
@@ -894,6 +895,7 @@ __global__ void __launch_bounds__(256, (Screen16Shape<KQ, TWO>::WAVES)) score_sc
     const int i_end = (int)min((int64_t)I, (int64_t)i_begin + ev.range_items);
     const bool shared_lists = ev.ranges > 1;
     half8_t ph[PER], pl[PER]; float preb;
+    const int frag0 = col * STR + 8 * quad;
     fetch(i_begin, ph, pl, preb);
     for (int item0 = i_begin; item0 < i_end; item0 += NI) {
         __syncthreads();
@@ -909,14 +911,16 @@ __global__ void __launch_bounds__(256, (Screen16Shape<KQ, TWO>::WAVES)) score_sc
         // the item fragments of a sub-step are read from LDS while the epilogue of the sub-step before it runs (into the
         // registers its MFMAs have just finished with): a wait for them at the top of every sub-step was 40 % of the kernel
         half8_t bh[NCH], bl[NCH]; float bj;
+        // (the lane's part of the address is formed once; per sub-step one addition of a scalar: the address arithmetic of
+        // (16 sub + col) * STR was five vector instructions per sub-step, one of them a 32-bit multiply, in a loop bound by vector issue)
         auto read_frags = [&](int sub) {
-            const int jj = sub * 16 + col;
+            const int at = frag0 + sub * (16 * STR);
 #pragma unroll
             for (int ch = 0; ch < NCH; ch++) {
-                bh[ch] = *reinterpret_cast<const half8_t*>(&tile_h[jj * STR + ch * 32 + 8 * quad]);
-                bl[ch] = *reinterpret_cast<const half8_t*>(&tile_l[jj * STR + ch * 32 + 8 * quad]);
+                bh[ch] = *reinterpret_cast<const half8_t*>(&tiles[at + ch * 32]);
+                bl[ch] = *reinterpret_cast<const half8_t*>(&tiles[NI * STR + at + ch * 32]);
             }
-            bj = tile_b[jj];
+            bj = tile_b[sub * 16 + col];
         };
         // (Writing the MFMAs of sub-step s + 1 next to the epilogue of sub-step s, so that the scheduler could interleave
         // them, was measured and changed nothing: 133.0 against 132.6 ms for 2M queries.)
