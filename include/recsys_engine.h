@@ -162,9 +162,16 @@ int rec_eval_sampled_per_user(rec_engine* e, int topn, int32_t n_sampled, uint64
 int rec_eval_sampled(rec_engine* e, int topn, int32_t n_sampled, uint64_t seed, rec_metrics* out, int32_t* counts_out,
                      int32_t* sampled_out);
 
-/* The ranking behind HIT@k (src/model.cpp:52-58): for every listed user, the k best-scored items among the
+/* The ranking behind HIT@k (src/model.cpp:32-58): for every listed user, the k best-scored items among the
  * candidates of model::AUC plus the context's positive, for the validation (index 0) and the test (index 1)
- * context.  items_out / scores_out: [n_users][2][k], best first; -1 / -inf when fewer than k exist. k <= 256. */
+ * context.  items_out / scores_out: [n_users][2][k], best first (score descending, item id ascending among equal
+ * scores); -1 / -inf when fewer than k exist.  k <= 256.  users = NULL: the first n_users users that have a test item,
+ * in ascending order (rec_eval reports how many there are).  scores_out may be NULL.
+ * With f32 tables and k <= 64 the lists come out of the full-catalog sweep itself: every query keeps the columns whose
+ * 16-bit-pipe score is within a proven bound of its running k-th best (one wavefront selects per query), the survivors
+ * are scored in fp64 and ordered exactly - any number of users, no score matrix ("topk_fused" 1, the default).
+ * Otherwise (f64 tables, k > 64, TransRec_L1, MostPopular, "topk_fused" 0, or a query with more near-ties than its
+ * list holds) the scores of a batch of users are written out [rows][n_items] in fp64 and selected from there. */
 int rec_eval_topk(rec_engine* e, const int32_t* users, int32_t n_users, int32_t k, int32_t* items_out, double* scores_out);
 
 /* Partial sums of rec_eval over this engine's users, for a sum all-reduce across ranks:
@@ -276,6 +283,8 @@ int rec_project_rows(rec_engine* e);
  *   "eval_ranges"   ranges the screen cuts the catalog into, each swept by its own blocks (0, the default: one range
  *                   unless the query blocks alone would not fill the chip evenly - few users per engine; then up to 16).  The
  *                   counts do not depend on it.  (process-wide)
+ *   "topk_fused"    1 (default) = rec_eval_topk takes its lists from the f16 sweep where that applies; 0 = always from the
+ *                   fp64 score matrix.  (process-wide)
  *   "profile"       time every update / scoring / sampler launch with HIP events */
 int rec_set_option(rec_engine* e, const char* name, int64_t value);
 
@@ -283,7 +292,9 @@ int rec_set_option(rec_engine* e, const char* name, int64_t value);
  * kernel together), 1 eval scoring kernel, 2 sampler, 3 the owner mode's partition alone.  Resets the counters.
  * which = 4 (not reset): how the last full-catalog sweep ran - *launches = 0 fp64, 1 the selected screen held, 2 a query
  * overflowed its list of undecided columns and fp64 took over, 3 the f16 screen overflowed and the f32 screen, tried next,
- * held; *total_ms = the number of columns the screen left to fp64, over all queries. */
+ * held; *total_ms = the number of columns the screen left to fp64, over all queries.
+ * which = 5 (not reset): the last rec_eval_topk - *launches = (user, context) lists produced by the fused sweep,
+ * *total_ms = device time of that part (HIP events around its kernels). */
 int rec_kernel_stats(rec_engine* e, int which, double* total_ms, int64_t* launches);
 
 #ifdef __cplusplus

@@ -243,11 +243,16 @@ class Engine:
         """TransRec: every item row back onto the unit ball (what an update launch does unless "project_after_launch" is 0)."""
         _check(lib().rec_project_rows(self.handle))
 
-    def eval_topk(self, users, k=50):
-        users = np.ascontiguousarray(users, np.int32)
-        items = np.zeros((len(users), 2, k), np.int32)
-        scores = np.zeros((len(users), 2, k), np.float64)
-        _check(lib().rec_eval_topk(self.handle, _p(users), C.c_int32(len(users)), C.c_int32(k), _p(items), _p(scores)))
+    def eval_topk(self, users, k=50, want_scores=True):
+        """users: an array of user ids, or an int n = the first n users that have a test item."""
+        if isinstance(users, (int, np.integer)):
+            n, users = int(users), None
+        else:
+            users = np.ascontiguousarray(users, np.int32)
+            n = len(users)
+        items = np.zeros((n, 2, k), np.int32)
+        scores = np.zeros((n, 2, k), np.float64) if want_scores else None
+        _check(lib().rec_eval_topk(self.handle, _p(users), C.c_int32(n), C.c_int32(k), _p(items), _p(scores)))
         return items, scores
 
     def eval_sums(self, topn=50):

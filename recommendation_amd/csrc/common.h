@@ -156,8 +156,11 @@ int eval_run(const DevModel& m, int precision, int32_t* counts_host, double* xpo
 
 // The k best-scored items of the validation and of the test context of every listed user:
 // items_host / scores_host are [n_users][2][k] (context 0 = validation, 1 = test; -1 / -inf past the end).
+// users_host == nullptr: the first n_users users of m.eval_users; scores_host may be nullptr.
 int eval_topk(const DevModel& m, int precision, const int32_t* users_host, int n_users, int k, int32_t* items_host,
               double* scores_host, hipStream_t st);
+void eval_configure_topk(int fused);                  // 1 (default): lists come out of the f16 sweep where it applies; 0: always the score-matrix path
+void eval_topk_stats(int64_t* lists, double* ms);     // of the last eval_topk: lists the fused path produced, and its device time
 
 #ifdef __HIPCC__
 // ---------------------------------------------------------------- device helpers

@@ -705,7 +705,7 @@ static int launch_update(rec_engine* e, const int4* tuples, int64_t n, double lr
                          : launch_sgd_hogwild(e->dm, e->desc.precision, tuples + o, len, lr, e->atomic | ((e->neg_share >= 4 ? 2 : (e->neg_share == 2 || e->pos_share == 2) ? 1 : 0) << 16), e->st);
         if (rc) return rc;
         if (global_row) {
-            if ((rc = launch_apply_global(e->dm, e->desc.precision, lr, len, (double)e->global_cap, e->st))) return rc;
+            if ((rc = launch_apply_global(e->dm, e->desc.precision, lr, len, (double)e->global_cap, e->st, e->project_after_launch != 0))) return rc;
             if ((rc = launch_apply_global_history(e->dm, e->desc.precision, lr, (double)e->global_cap, e->st))) return rc;
         }
     }
@@ -1032,14 +1032,18 @@ extern "C" int rec_eval_sums(rec_engine* e, int topn, double sums[8])
 
 extern "C" int rec_eval_topk(rec_engine* e, const int32_t* users, int32_t n_users, int32_t k, int32_t* items_out, double* scores_out)
 {
-    if (!e || !users || !items_out || !scores_out) { rec_set_error("null argument"); return -1; }
+    if (!e || !items_out) { rec_set_error("null argument"); return -1; }
     if (n_users <= 0) return 0;
     ENG_HIP(hipSetDevice(e->desc.device));
     ENG_HIP(hipStreamSynchronize(e->st));
-    std::vector<int32_t> test(e->U);
-    ENG_HIP(hipMemcpy(test.data(), e->dm.test_item, sizeof(int32_t) * e->U, hipMemcpyDeviceToHost));
-    for (int i = 0; i < n_users; i++)
-        if (users[i] < e->desc.user_begin || users[i] >= e->desc.user_end || test[users[i]] < 0) { rec_set_error("user " + std::to_string(users[i]) + " has no validation / test item"); return -1; }
+    if (users) {
+        std::vector<int32_t> test(e->U);
+        ENG_HIP(hipMemcpy(test.data(), e->dm.test_item, sizeof(int32_t) * e->U, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n_users; i++)
+            if (users[i] < e->desc.user_begin || users[i] >= e->desc.user_end || test[users[i]] < 0) { rec_set_error("user " + std::to_string(users[i]) + " has no validation / test item"); return -1; }
+    } else if (n_users > e->dm.n_eval) {
+        rec_set_error("n_users exceeds the " + std::to_string(e->dm.n_eval) + " users that have a test item"); return -1;
+    }
     return eval_topk(e->dm, e->desc.precision, users, n_users, k, items_out, scores_out, e->st);
 }
 
@@ -1288,6 +1292,7 @@ extern "C" int rec_set_option(rec_engine* e, const char* name, int64_t value)
     else if (s == "owner_flush") { if (value < 1 || value > 65536) { rec_set_error("owner_flush must be in 1..65536"); return -1; } e->owner_flush = (int)value; }
     else if (s == "owner_per_item") { if (value < 1) { rec_set_error("owner_per_item must be positive"); return -1; } e->owner_per_item = value; }
     else if (s == "eval_screen") { if (value < 0 || value > 2) { rec_set_error("eval_screen must be 0, 1 or 2"); return -1; } eval_configure_screen((int)value, -1); }
+    else if (s == "topk_fused") { if (value != 0 && value != 1) { rec_set_error("topk_fused must be 0 or 1"); return -1; } eval_configure_topk((int)value); }
     else if (s == "eval_ranges") { if (value < 0 || value > 64) { rec_set_error("eval_ranges must be in 0..64"); return -1; } eval_configure_ranges((int)value); }
     else if (s == "eval_screen_cap") { if (value < 0 || value > 4096) { rec_set_error("eval_screen_cap must be in 0..4096"); return -1; } eval_configure_screen(-1, (int)value); }
     else if (s == "owner_slices") { if (value != 0 && value != 256 && value != 512 && value != 1024) { rec_set_error("owner_slices must be 0, 256, 512 or 1024"); return -1; } e->owner_slices = (int)value; }
@@ -1311,7 +1316,7 @@ extern "C" int rec_set_option(rec_engine* e, const char* name, int64_t value)
 
 extern "C" int rec_kernel_stats(rec_engine* e, int which, double* total_ms, int64_t* launches)
 {
-    if (!e || which < 0 || which > 4) { rec_set_error("bad argument"); return -1; }
+    if (!e || which < 0 || which > 5) { rec_set_error("bad argument"); return -1; }
     ENG_HIP(hipSetDevice(e->desc.device));
     ENG_HIP(hipStreamSynchronize(e->st));
     if (which == 4) {
@@ -1319,6 +1324,13 @@ extern "C" int rec_kernel_stats(rec_engine* e, int which, double* total_ms, int6
         eval_screen_stats(&mode, &open);
         if (total_ms) *total_ms = (double)open;
         if (launches) *launches = mode;
+        return 0;
+    }
+    if (which == 5) {
+        int64_t lists = 0; double ms = 0;
+        eval_topk_stats(&lists, &ms);
+        if (total_ms) *total_ms = ms;
+        if (launches) *launches = lists;
         return 0;
     }
     for (auto& p : e->pending[which]) {

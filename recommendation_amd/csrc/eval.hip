@@ -14,6 +14,7 @@
 // walks the user's (short) click list.
 #include "common.h"
 #include <math.h>
+#include <string.h>
 #include <vector>
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -1802,11 +1803,550 @@ static int topk_impl(const DevModel& m0, const int32_t* users_host, int n_users,
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Top-k lists fused into the sweep (f32 tables, k <= 64): no score matrix.  The f16 sweep above, with ONE moving threshold
+// per query instead of the positive's score.  A query keeps a list of at most TOPK_CAP candidate columns (approximate
+// score, item) per catalog range; a column enters when its approximate score is not below the query's bar
+//     bar = tau - 2 M,     tau = the k-th best approximate score among the candidates seen so far (clicked and held-out
+//                                items left out), M = the query's proven bound on |approximate - exact|,
+// and whenever a list is nearly full the wavefront that owns the query selects the k-th best of it (a 32-step search
+// over the bit patterns, counted with ballots), raises the bar and drops what fell below it.  Why 2 M: the k candidates
+// at or above tau have exact scores >= tau - M, so the exact k-th best is >= tau - M, and a column of the exact top k
+// has an approximate score >= tau - 2 M - it is never refused and never dropped.  The lists therefore always hold a
+// superset of the exact top k; topk_finish_kernel scores the survivors in fp64 (the summation of correct_clicked_kernel)
+// and orders them exactly (score descending, item id ascending).  Appends are rare after the first few thousand columns
+// (the bar follows the k-th best of everything seen), so the hot epilogue is one subtraction and half a v_min3 per score.
+// A list that stays nearly full after a selection (more than TOPK_CAP - 16 columns within 2 M of the k-th best) marks
+// its query for the caller's fallback, the score-matrix path.
+#define TOPK_CAP 256
+#define TOPK_NEG_BIG (-3.0e38f)
+
+struct TopkDev {
+    int k, ranges;
+    unsigned long long* cand;   // [nq_pad * ranges][TOPK_CAP]: item << 32 | bit pattern of the approximate (scaled) score
+    int32_t* cand_cnt;          // [nq_pad * ranges]
+    int32_t* q_over;            // [nq_pad] 1: the query's lists could not hold its near-ties
+    const int4* qmeta;          // [nq_pad] (user, positive, the other held-out item, -); user -1 on padding rows
+    int32_t* items_out;         // [nq][k]
+    double* scores_out;         // [nq][k]
+};
+
+// bit patterns of floats as unsigned keys that order like the floats (larger float, larger key); NaN patterns with the
+// sign bit set map to keys near 0, and 0xffffffff - the mark of a dropped entry - to key 0
+__device__ __forceinline__ unsigned f32_key(unsigned b) { return (b >> 31) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ unsigned f32_unkey(unsigned k) { return (k >> 31) ? (k & 0x7fffffffu) : ~k; }
+
+__global__ void topk_meta_kernel(DevModel m, EvalDev ev, int4* __restrict__ qmeta)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ev.nq_pad) return;
+    int4 r = make_int4(-1, -1, -1, 0);
+    if (i < ev.nq) {
+        const int u = m.eval_users[i >> 1]; const int ctx = (int)(i & 1);
+        const int val = m.val_item[u], test = m.test_item[u];
+        r = make_int4(u, ctx ? test : val, ctx ? val : test, 0);
+    }
+    qmeta[i] = r;
+}
+
+// query planes and margins for the top-k sweep: screen16_queries_kernel without thresholds (the moving bar is itself an
+// approximate score, bounded by Bmax + ||q'|| Tmax like every score)
+__global__ void __launch_bounds__(256) topk16_queries_kernel(EvalDev ev, int KQ16, const unsigned* __restrict__ bounds, half_t* __restrict__ Qh,
+                                                             half_t* __restrict__ Ql, int32_t* __restrict__ overflow)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w >= ev.nq_pad) return;
+    const double sT = screen16_scale(bounds[2]), sq = screen16_scale(bounds[3]), S = sq * sT;
+    double s = 0;
+    for (int k = lane; k < KQ16; k += 64) {
+        const double q = k < ev.KQ ? ev.Q[w * ev.KQ + k] : 0.0;
+        s += q * q;
+        half_t h, l; split16((float)(q * sq), h, l);
+        Qh[w * KQ16 + k] = h; Ql[w * KQ16 + k] = l;
+    }
+    s = sqrt(group_sum<64>(s));
+    if (lane == 0) {
+        const double tmax = (double)__uint_as_float(bounds[0]), bmax = (double)__uint_as_float(bounds[1]);
+        const double u = 5.9604644775390625e-08;   // 2^-24
+        const double rep = 3.3 * 4.0 * u * s * tmax;
+        const double sub = 6.103515625e-05 * sqrt((double)KQ16) * (tmax / sq + s / sT);
+        const double acc = 2.0 * (KQ16 + 3) * u * 1.002 * s * tmax + KQ16 * (u / 64.0) * s * tmax;
+        const double rnd = 8.0 * u * (bmax + s * tmax);
+        const double mq = 1.05 * (rep + sub + acc + rnd) + 1e-30;
+        ev.qmar[w] = w < ev.nq ? __double2float_ru(mq * S * 1.000001) : 0.f;
+        if (w < ev.nq && !((bmax + s * tmax + mq) * S <= 1e30)) *overflow = 1;   // scores must stay far from the end of f32's range (and finite)
+    }
+}
+
+template <int KQ>
+__global__ void __launch_bounds__(256, 2) topk_sweep16_kernel(EvalDev ev, TopkDev tk, const int64_t* __restrict__ clk_off, const int32_t* __restrict__ clk_item,
+                                                              const half_t* __restrict__ Th, const half_t* __restrict__ Tl, const float* __restrict__ bs,
+                                                              const half_t* __restrict__ Qh, const half_t* __restrict__ Ql, int I)
+{
+    constexpr int MT = Screen16Shape<KQ, false>::MT, NI = Screen16Shape<KQ, false>::NI, QB = Screen16Shape<KQ, false>::QB;
+    constexpr int NCH = KQ / 32, STR = KQ + 8, PER = NI * KQ / 8 / 256;
+    static_assert(PER >= 1 && KQ % 32 == 0 && MT * 16 <= 64, "tile shape");
+    __shared__ __align__(16) half_t tiles[2 * NI * STR];
+    half_t* const tile_h = tiles;
+    half_t* const tile_l = tiles + NI * STR;
+    __shared__ float tile_b[NI];
+    __shared__ int q_cnt[QB];                 // entries in each query's list (this block's range)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, quad = lane >> 4;
+    const int64_t qblock = (int64_t)blockIdx.x * QB;
+    const int qw = wave * (MT * 16);
+    const int k = tk.k;
+
+    for (int i = tid; i < QB; i += 256) q_cnt[i] = 0;
+    // bar[mt][r]: a column is listed when its score is not below it.  One margin per wavefront, the largest of its queries'.
+    float bar[MT][4], marw = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int64_t qi = qblock + qw + mt * 16 + 4 * quad + r;
+            marw = fmaxf(marw, ev.qmar[qi]);
+            bar[mt][r] = tk.qmeta[qi].x >= 0 ? TOPK_NEG_BIG : INFINITY;     // a padding row lists nothing
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) marw = fmaxf(marw, __shfl_xor(marw, o, 64));
+    const float mar_w = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(marw)));
+
+    half8_t ah[MT][NCH], al[MT][NCH];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {
+            const int64_t at = (qblock + qw + mt * 16 + col) * KQ + ch * 32 + 8 * quad;
+            ah[mt][ch] = *reinterpret_cast<const half8_t*>(Qh + at);
+            al[mt][ch] = *reinterpret_cast<const half8_t*>(Ql + at);
+        }
+
+    auto fetch = [&](int item0, half8_t (&ph)[PER], half8_t (&pl)[PER], float& preb) {
+#pragma unroll
+        for (int p = 0; p < PER; p++) {
+            const int64_t at = (int64_t)item0 * KQ + 8 * (int64_t)(tid + 256 * p);
+            ph[p] = *reinterpret_cast<const half8_t*>(Th + at);
+            pl[p] = *reinterpret_cast<const half8_t*>(Tl + at);
+        }
+        preb = tid < NI ? bs[item0 + tid] : 0.f;
+    };
+
+    // The wavefront that owns query qi (a row of this block) raises its bar: the k-th best of the list, clicked and
+    // held-out items dropped, then everything below the new bar.  Returns the new bar.
+    auto select = [&](int qi) -> float {
+        const int64_t qg = qblock + qi;
+        unsigned long long* base = tk.cand + (qg * tk.ranges + blockIdx.y) * TOPK_CAP;
+        const int n = min(q_cnt[qi], TOPK_CAP);
+        const int4 meta = tk.qmeta[qg];
+        const int32_t* clk = clk_item + clk_off[meta.x]; const int nc = (int)(clk_off[meta.x + 1] - clk_off[meta.x]);
+        __threadfence();                       // the appends of this wavefront have reached memory
+        unsigned long long ent[TOPK_CAP / 64]; unsigned key[TOPK_CAP / 64];
+#pragma unroll
+        for (int i = 0; i < TOPK_CAP / 64; i++) {
+            const int idx = lane + 64 * i;
+            // a load that does not stop at this compute unit's vector cache (which may hold the line as an earlier selection read it)
+            ent[i] = idx < n ? __hip_atomic_load(base + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffull;
+            const int item = (int)(ent[i] >> 32);
+            const bool ok = idx < n && item != meta.y && item != meta.z && !sorted_contains(clk, nc, item);
+            key[i] = ok ? f32_key((unsigned)ent[i]) : 0u;
+        }
+        unsigned prefix = 0;                   // the largest v with at least k keys >= v (0: fewer than k valid entries)
+#pragma unroll 1
+        for (int bit = 31; bit >= 0; bit--) {
+            const unsigned v = prefix | (1u << bit);
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < TOPK_CAP / 64; i++) c += __popcll(__ballot(key[i] >= v));
+            if (c >= k) prefix = v;
+        }
+        float nb = TOPK_NEG_BIG;
+        if (prefix) {
+            const float tau = __uint_as_float(f32_unkey(prefix));
+            nb = (tau - 2.f * mar_w) - 2.4e-7f * (fabsf(tau) + 2.f * mar_w);
+        }
+        int off = 0;
+#pragma unroll
+        for (int i = 0; i < TOPK_CAP / 64; i++) {
+            const bool keep = key[i] != 0u && __uint_as_float((unsigned)ent[i]) >= nb;
+            const unsigned long long bal = __ballot(keep);
+            if (keep) base[off + __popcll(bal & ((1ull << lane) - 1ull))] = ent[i];
+            off += __popcll(bal);
+        }
+        if (off > TOPK_CAP - 16) {             // too many columns within the margin of the k-th best: the caller's fallback decides this query
+            if (lane == 0) tk.q_over[qg] = 1;
+            off = 0; nb = INFINITY;
+        }
+        if (lane == 0) q_cnt[qi] = off;
+        return nb;
+    };
+
+    const int i_begin = (int)blockIdx.y * ev.range_items;
+    const int i_end = (int)min((int64_t)I, (int64_t)i_begin + ev.range_items);
+    half8_t ph[PER], pl[PER]; float preb;
+    const int frag0 = col * STR + 8 * quad;
+    fetch(i_begin, ph, pl, preb);
+    for (int item0 = i_begin; item0 < i_end; item0 += NI) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < PER; p++) {
+            const int e = 8 * (tid + 256 * p), it = e / KQ, kk = e % KQ;
+            *reinterpret_cast<half8_t*>(&tile_h[it * STR + kk]) = ph[p];
+            *reinterpret_cast<half8_t*>(&tile_l[it * STR + kk]) = pl[p];
+        }
+        if (tid < NI) tile_b[tid] = preb;
+        __syncthreads();
+        if (item0 + NI < i_end) fetch(item0 + NI, ph, pl, preb);
+        half8_t bh[NCH], bl[NCH]; float bj;
+        auto read_frags = [&](int sub) {
+            const int at = frag0 + sub * (16 * STR);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ch++) {
+                bh[ch] = *reinterpret_cast<const half8_t*>(&tiles[at + ch * 32]);
+                bl[ch] = *reinterpret_cast<const half8_t*>(&tiles[NI * STR + at + ch * 32]);
+            }
+            bj = tile_b[sub * 16 + col];
+        };
+        read_frags(0);
+#pragma unroll 1
+        for (int sub = 0; sub < NI / 16; sub++) {
+            const int j = item0 + sub * 16 + col;
+            float sc[MT][4];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                float4_t am = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ch = 0; ch < NCH; ch++) {
+                    am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt][ch], bl[ch], am, 0, 0, 0);
+                    am = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt][ch], bh[ch], am, 0, 0, 0);
+                }
+#pragma unroll
+                for (int ch = 0; ch < NCH; ch++) am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt][ch], bh[ch], am, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) sc[mt][r] = am[r] + bj;
+            }
+            if (sub + 1 < NI / 16) read_frags(sub + 1);
+            // y = score - bar: non-negative and finite <=> listed (a column past the end of the catalog scores +inf; a
+            // padding row's bar is +inf).  As unsigned integers those patterns are the ones <= 0x7f7fffff.
+            unsigned mn = 0xffffffffu;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+#pragma unroll
+                for (int r = 0; r < 4; r += 2) {
+                    const unsigned y0 = __float_as_uint(sc[mt][r] - bar[mt][r]), y1 = __float_as_uint(sc[mt][r + 1] - bar[mt][r + 1]);
+                    mn = min(min(mn, y0), y1);   // one v_min3_u32
+                }
+            }
+            if (!__ballot(mn <= 0x7f7fffffu)) continue;
+            bool full = false;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const bool in = __float_as_uint(sc[mt][r] - bar[mt][r]) <= 0x7f7fffffu;
+                    if (!__ballot(in)) continue;
+                    if (in) {
+                        const int qi = qw + mt * 16 + 4 * quad + r;
+                        const int at = atomicAdd(&q_cnt[qi], 1);
+                        if (at < TOPK_CAP)
+                            tk.cand[((qblock + qi) * tk.ranges + blockIdx.y) * TOPK_CAP + at] = ((unsigned long long)(unsigned)j << 32) | __float_as_uint(sc[mt][r]);
+                        full |= at + 1 > TOPK_CAP - 16;   // a sub-step adds at most 16 columns to a list: selected before the next one
+                    }
+                }
+            if (!__ballot(full)) continue;
+            unsigned long long need = __ballot(lane < MT * 16 && q_cnt[qw + (lane < MT * 16 ? lane : 0)] > TOPK_CAP - 16);
+            while (need) {
+                const int ql = __ffsll((long long)need) - 1;
+                need &= need - 1;
+                const float nb = select(qw + ql);
+                const int tmt = ql >> 4, tq = (ql & 15) >> 2, tr = ql & 3;
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (mt == tmt && r == tr && quad == tq) bar[mt][r] = nb;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < QB; i += 256) tk.cand_cnt[(qblock + i) * tk.ranges + blockIdx.y] = min(q_cnt[i], TOPK_CAP);
+}
+
+// One wavefront per query: the k best of its lists, exactly.  Drops clicked / held-out items, finds the k-th best
+// approximate score over all ranges, scores what is within 2 M of it in fp64 (four items per step, 16 lanes each: the
+// summation of correct_clicked_kernel), adds the context's positive with the score the reference formula gives it, and
+// orders by (score descending, item id ascending).
+#define TOPK_SURV 192
+template <class T>
+__global__ void __launch_bounds__(256) topk_finish_kernel(DevModel m, EvalDev ev, TopkDev tk)
+{
+    __shared__ int s_item[4][TOPK_SURV];
+    __shared__ double s_score[4][TOPK_SURV];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l16 = lane & 15, gq = lane >> 4;
+    const int w = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (w >= ev.nq) return;
+    const int k = tk.k;
+    int32_t* items = tk.items_out + (int64_t)w * k;
+    double* scores = tk.scores_out + (int64_t)w * k;
+    const int4 meta = tk.qmeta[w];
+    const int32_t* clk = m.clk_item + m.clk_off[meta.x]; const int nc = (int)(m.clk_off[meta.x + 1] - m.clk_off[meta.x]);
+    unsigned long long* lists = tk.cand + (int64_t)w * tk.ranges * TOPK_CAP;
+    const int32_t* cnts = tk.cand_cnt + (int64_t)w * tk.ranges;
+    bool over = tk.q_over[w] != 0;
+    // entries that are not candidates get the pattern of key 0
+    for (int r = 0; r < tk.ranges; r++) {
+        const int n = cnts[r];
+        for (int idx = lane; idx < n; idx += 64) {
+            const unsigned long long e = lists[r * TOPK_CAP + idx];
+            const int item = (int)(e >> 32);
+            if (item == meta.y || item == meta.z || sorted_contains(clk, nc, item)) lists[r * TOPK_CAP + idx] = e | 0xffffffffull;
+        }
+    }
+    __threadfence();
+    unsigned prefix = 0;
+#pragma unroll 1
+    for (int bit = 31; bit >= 0 && !over; bit--) {
+        const unsigned v = prefix | (1u << bit);
+        int c = 0;
+        for (int r = 0; r < tk.ranges; r++) {
+            const int n = cnts[r];
+            for (int i0 = 0; i0 < n; i0 += 64) {
+                const int idx = i0 + lane;
+                const unsigned key = idx < n ? f32_key((unsigned)__hip_atomic_load(lists + r * TOPK_CAP + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0u;
+                c += __popcll(__ballot(key >= v));
+            }
+        }
+        if (c >= k) prefix = v;
+    }
+    float nb = TOPK_NEG_BIG;
+    if (prefix) {
+        const float tau = __uint_as_float(f32_unkey(prefix)), mq = ev.qmar[w];
+        nb = (tau - 2.f * mq) - 2.4e-7f * (fabsf(tau) + 2.f * mq);
+    }
+    int ns = 0;
+    for (int r = 0; r < tk.ranges && !over; r++) {
+        const int n = cnts[r];
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int idx = i0 + lane;
+            const unsigned long long e = idx < n ? __hip_atomic_load(lists + r * TOPK_CAP + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffull;
+            const bool keep = f32_key((unsigned)e) != 0u && __uint_as_float((unsigned)e) >= nb;
+            const unsigned long long bal = __ballot(keep);
+            const int at = ns + __popcll(bal & ((1ull << lane) - 1ull));
+            if (keep && at < TOPK_SURV - 1) s_item[wv][at] = (int)(e >> 32);
+            ns += __popcll(bal);
+        }
+    }
+    if (ns > TOPK_SURV - 1) over = true;
+    if (over) {
+        // left to the caller's fallback
+        if (lane == 0) tk.q_over[w] = 1;
+        for (int r = lane; r < k; r += 64) { items[r] = -1; scores[r] = -INFINITY; }
+        return;
+    }
+    const double* q = ev.Q + (int64_t)w * ev.KQ;
+    const T* seg0 = ev.seg0 >= 0 ? (const T*)m.tab[ev.seg0] : nullptr;
+    const T* seg1 = ev.seg1 >= 0 ? (const T*)m.tab[ev.seg1] : nullptr;
+    const int K1 = ev.K1, K2 = ev.K2;
+    for (int base = 0; base < ns; base += 4) {
+        const int idx = base + gq;
+        const int64_t ec = idx < ns ? s_item[wv][idx] : 0;
+        double s = 0;
+        for (int kk = l16; kk < K1; kk += 16) s += q[kk] * (double)seg0[ec * K1 + kk];
+        for (int kk = l16; kk < K2; kk += 16) s += q[K1 + kk] * (double)seg1[ec * K2 + kk];
+        s = group_sum<16>(s) + ev.bconst[ec];
+        if (l16 == 0 && idx < ns) s_score[wv][idx] = s;
+    }
+    if (lane == 0) { s_item[wv][ns] = meta.y; s_score[wv][ns] = ev.thr[w]; }
+    const int nt = ns + 1;
+    const double aq = ev.aq[w];
+    // LDS writes of this wavefront are visible to its later reads (in order); rank by counting
+    for (int i = lane; i < nt; i += 64) {
+        const double si = s_score[wv][i]; const int ii = s_item[wv][i];
+        int rank = 0;
+        for (int x = 0; x < nt; x++) { const double sx = s_score[wv][x]; rank += (sx > si || (sx == si && s_item[wv][x] < ii)) ? 1 : 0; }
+        if (rank < k) { items[rank] = ii; scores[rank] = si + aq; }
+    }
+    for (int r = nt + lane; r < k; r += 64) { items[r] = -1; scores[r] = -INFINITY; }
+}
+
+static int g_topk_fused = 1;
+static int64_t g_topk_fused_lists = 0; static double g_topk_fused_ms = 0;
+void eval_configure_topk(int fused) { g_topk_fused = fused; }
+void eval_topk_stats(int64_t* lists, double* ms) { *lists = g_topk_fused_lists; *ms = g_topk_fused_ms; }
+
+template <int KQ>
+static void launch_topk_sweep(const EvalDev& ev, const TopkDev& tk, const DevModel& m, const half_t* Th, const half_t* Tl, const float* bs, const half_t* Qh,
+                              const half_t* Ql, hipStream_t st)
+{
+    const unsigned blocks = (unsigned)(ev.nq_pad / Screen16Shape<KQ, false>::QB);
+    hipLaunchKernelGGL((topk_sweep16_kernel<KQ>), dim3(blocks, ev.ranges), dim3(256), 0, st, ev, tk, m.clk_off, m.clk_item, Th, Tl, bs, Qh, Ql, m.I);
+}
+
+// users_host == nullptr: the first n_users users of m.eval_users.  fallback: positions (in users order) whose lists the
+// fused path could not produce; *all_fallback: the operands do not suit the f16 sweep at all.
+static int topk_fused_impl(const DevModel& m0, const int32_t* users_host, int n_users, int k, int32_t* items_host, double* scores_host,
+                           hipStream_t st, std::vector<int32_t>& fallback, bool* all_fallback)
+{
+    typedef float T;
+    DevModel m = m0;
+    const int I = m.I;
+    *all_fallback = false;
+    EvalDev ev = {};
+    ev.nctx = 2; ev.force2 = 1;
+    ev.seg0 = ev.seg1 = -1; ev.K1 = ev.K2 = 0;
+    switch (m.model) {
+    case REC_BPRMF: ev.seg0 = BPRMF_GI; ev.K1 = m.K; break;
+    case REC_MC: ev.seg0 = MC_ETA; ev.K1 = m.K; break;
+    case REC_FPMC: ev.seg0 = FPMC_GI; ev.K1 = m.K; ev.seg1 = FPMC_ETA; ev.K2 = m.KK; break;
+    case REC_PRME: ev.seg0 = PRME_GI; ev.K1 = m.K; ev.seg1 = PRME_ETA; ev.K2 = m.KK; break;
+    case REC_HRM_AVG: case REC_HRM_MAX: ev.seg0 = HRM_V; ev.K1 = m.K; break;
+    case REC_TRANSREC: ev.seg0 = TR_H; ev.K1 = m.K; break;
+    case REC_FOSSIL_SIMPLE: ev.seg0 = FS_V; ev.K1 = m.K; break;
+    case REC_FOSSIL: ev.seg0 = FO_V; ev.K1 = m.K; break;
+    case REC_REBUS: ev.seg0 = RB_P; ev.K1 = m.K; break;
+    default: *all_fallback = true; return 0;
+    }
+    const int kw = ev.K1 + ev.K2;
+    ev.KQ = kw <= 16 ? 16 : kw <= 32 ? 32 : kw <= 64 ? 64 : kw <= 128 ? 128 : 256;
+    const int KQ16 = std::max(32, ev.KQ);
+    const int QBLK = screen16_qb(KQ16, false);
+    const int NI16 = KQ16 <= 128 ? 64 : 32;
+    const int I_pad = ((I + NI16 - 1) / NI16) * NI16;
+    const int batch_users = std::min(n_users, 1 << 19);
+    const int max_rows = ((2 * batch_users + QBLK - 1) / QBLK) * QBLK;
+    // catalog ranges: enough blocks to fill the chip when the queries alone do not (a short list of users)
+    int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    {
+        const int64_t blocks = max_rows / QBLK, resident = 2 * (int64_t)cus;
+        const int tile = 128;
+        int ranges = (int)std::min<int64_t>(std::min<int64_t>(64, (4 * resident + blocks - 1) / blocks), (I + 4095) / 4096);
+        ranges = std::max(1, ranges);
+        ev.range_items = (int)((((int64_t)I + ranges - 1) / ranges + tile - 1) / tile * tile);
+        ev.ranges = (I + ev.range_items - 1) / ev.range_items;
+    }
+    std::vector<void*> owned;
+    auto alloc = [&](void** p, size_t bytes) -> hipError_t { hipError_t e = hipMalloc(p, bytes ? bytes : 8); if (e == hipSuccess) owned.push_back(*p); return e; };
+    auto release = [&]() { for (void* p : owned) (void)hipFree(p); };
+#define TF_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { rec_set_error(std::string(#expr) + ": " + hipGetErrorString(_e)); release(); return -2; } } while (0)
+    TopkDev tk = {};
+    tk.k = k; tk.ranges = ev.ranges;
+    int32_t* d_users = nullptr; int4* qmeta = nullptr; int32_t* over = nullptr; unsigned* b4 = nullptr;
+    half_t *Th = nullptr, *Tl = nullptr, *Qh = nullptr, *Ql = nullptr; float* bs = nullptr;
+    if (users_host) TF_TRY(alloc((void**)&d_users, sizeof(int32_t) * batch_users));
+    TF_TRY(alloc((void**)&ev.Q, sizeof(double) * (size_t)max_rows * ev.KQ));
+    TF_TRY(alloc((void**)&ev.thr, sizeof(double) * max_rows));
+    TF_TRY(alloc((void**)&ev.thr2, sizeof(double) * max_rows));
+    TF_TRY(alloc((void**)&ev.aq, sizeof(double) * max_rows));
+    TF_TRY(alloc((void**)&ev.qmar, sizeof(float) * max_rows));
+    TF_TRY(alloc((void**)&ev.bconst, sizeof(double) * I));
+    TF_TRY(alloc((void**)&ev.xpos, sizeof(double) * (size_t)m.U * 2));
+    TF_TRY(alloc((void**)&qmeta, sizeof(int4) * max_rows));
+    TF_TRY(alloc((void**)&tk.cand, sizeof(unsigned long long) * (size_t)max_rows * ev.ranges * TOPK_CAP));
+    TF_TRY(alloc((void**)&tk.cand_cnt, sizeof(int32_t) * (size_t)max_rows * ev.ranges));
+    TF_TRY(alloc((void**)&tk.q_over, sizeof(int32_t) * max_rows));
+    TF_TRY(alloc((void**)&tk.items_out, sizeof(int32_t) * (size_t)max_rows * k));
+    TF_TRY(alloc((void**)&tk.scores_out, sizeof(double) * (size_t)max_rows * k));
+    TF_TRY(alloc((void**)&over, sizeof(int32_t)));
+    TF_TRY(alloc((void**)&b4, sizeof(unsigned) * 4));
+    TF_TRY(alloc((void**)&Th, sizeof(half_t) * (size_t)I_pad * KQ16));
+    TF_TRY(alloc((void**)&Tl, sizeof(half_t) * (size_t)I_pad * KQ16));
+    TF_TRY(alloc((void**)&bs, sizeof(float) * (size_t)I_pad));
+    TF_TRY(alloc((void**)&Qh, sizeof(half_t) * (size_t)max_rows * KQ16));
+    TF_TRY(alloc((void**)&Ql, sizeof(half_t) * (size_t)max_rows * KQ16));
+    tk.qmeta = qmeta;
+    ev.col_b = ev.bconst; ev.n_cols = I;
+    const float* seg0 = ev.seg0 >= 0 ? (const float*)m.tab[ev.seg0] : nullptr;
+    const float* seg1 = ev.seg1 >= 0 ? (const float*)m.tab[ev.seg1] : nullptr;
+    hipLaunchKernelGGL(item_consts_kernel<T>, dim3(blocks_for_waves(I)), dim3(256), 0, st, m, ev);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    TF_TRY(hipEventCreate(&e0)); TF_TRY(hipEventCreate(&e1));
+    std::vector<int32_t> over_host;
+    g_topk_fused_lists = 0; g_topk_fused_ms = 0;
+    const int32_t* all_users = m0.eval_users;
+    for (int u0 = 0; u0 < n_users; u0 += batch_users) {
+        const int nu = std::min(batch_users, n_users - u0);
+        if (users_host) { TF_TRY(hipMemcpyAsync(d_users, users_host + u0, sizeof(int32_t) * nu, hipMemcpyHostToDevice, st)); m.eval_users = d_users; }
+        else m.eval_users = all_users + u0;
+        m.n_eval = nu;
+        ev.nq = 2 * nu; ev.nq_pad = ((ev.nq + QBLK - 1) / QBLK) * QBLK;
+        TF_TRY(hipEventRecord(e0, st));
+        TF_TRY(hipMemsetAsync(ev.Q, 0, sizeof(double) * (size_t)ev.nq_pad * ev.KQ, st));
+        TF_TRY(hipMemsetAsync(tk.q_over, 0, sizeof(int32_t) * ev.nq_pad, st));
+        TF_TRY(hipMemsetAsync(over, 0, sizeof(int32_t), st));
+        TF_TRY(hipMemsetAsync(b4, 0, sizeof(unsigned) * 4, st));
+        hipLaunchKernelGGL(topk_meta_kernel, dim3((ev.nq_pad + 255) / 256), dim3(256), 0, st, m, ev, qmeta);
+        hipLaunchKernelGGL(build_queries_kernel<T>, dim3(blocks_for_waves(ev.nq)), dim3(256), 0, st, m, ev);
+        hipLaunchKernelGGL(screen16_bounds_kernel, dim3(1024), dim3(256), 0, st, ev, seg0, seg1, I, b4);
+        hipLaunchKernelGGL(screen16_items_kernel, dim3(2048), dim3(256), 0, st, ev, seg0, seg1, I, I_pad, KQ16, (const unsigned*)b4, Th, Tl, bs, over);
+        hipLaunchKernelGGL(topk16_queries_kernel, dim3(blocks_for_waves(ev.nq_pad)), dim3(256), 0, st, ev, KQ16, (const unsigned*)b4, Qh, Ql, over);
+        switch (KQ16) {
+        case 32: launch_topk_sweep<32>(ev, tk, m, Th, Tl, bs, Qh, Ql, st); break;
+        case 64: launch_topk_sweep<64>(ev, tk, m, Th, Tl, bs, Qh, Ql, st); break;
+        case 128: launch_topk_sweep<128>(ev, tk, m, Th, Tl, bs, Qh, Ql, st); break;
+        default: launch_topk_sweep<256>(ev, tk, m, Th, Tl, bs, Qh, Ql, st); break;
+        }
+        hipLaunchKernelGGL(topk_finish_kernel<T>, dim3(blocks_for_waves(ev.nq)), dim3(256), 0, st, m, ev, tk);
+        TF_TRY(hipGetLastError());
+        TF_TRY(hipEventRecord(e1, st));
+        int32_t ov = 0;
+        over_host.resize(ev.nq);
+        TF_TRY(hipMemcpyAsync(&ov, over, sizeof ov, hipMemcpyDeviceToHost, st));
+        TF_TRY(hipMemcpyAsync(over_host.data(), tk.q_over, sizeof(int32_t) * ev.nq, hipMemcpyDeviceToHost, st));
+        TF_TRY(hipMemcpyAsync(items_host + (size_t)u0 * 2 * k, tk.items_out, sizeof(int32_t) * (size_t)ev.nq * k, hipMemcpyDeviceToHost, st));
+        if (scores_host) TF_TRY(hipMemcpyAsync(scores_host + (size_t)u0 * 2 * k, tk.scores_out, sizeof(double) * (size_t)ev.nq * k, hipMemcpyDeviceToHost, st));
+        TF_TRY(hipStreamSynchronize(st));
+        float ms = 0; TF_TRY(hipEventElapsedTime(&ms, e0, e1)); g_topk_fused_ms += ms;
+        if (ov) {   // tables or queries that are not finite, or out of the f16 sweep's range
+            *all_fallback = true;
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); release();
+            g_topk_fused_lists = 0;
+            return 0;
+        }
+        for (int a = 0; a < nu; a++) {
+            if (over_host[2 * a] || over_host[2 * a + 1]) fallback.push_back(u0 + a);
+            else g_topk_fused_lists += 2;
+        }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    release();
+#undef TF_TRY
+    return 0;
+}
+
 int eval_topk(const DevModel& m, int precision, const int32_t* users_host, int n_users, int k, int32_t* items_host,
               double* scores_host, hipStream_t st)
 {
-    return precision == REC_F64 ? topk_impl<double>(m, users_host, n_users, k, items_host, scores_host, st)
-                                : topk_impl<float>(m, users_host, n_users, k, items_host, scores_host, st);
+    if (k < 1 || k > 256) { rec_set_error("k must be in 1..256"); return -1; }
+    g_topk_fused_lists = 0; g_topk_fused_ms = 0;
+    std::vector<int32_t> all;
+    if (!users_host && (n_users < 0 || n_users > m.n_eval)) { rec_set_error("more users than have a test item"); return -1; }
+    const bool fused = g_topk_fused && precision == REC_F32 && k <= 64 && m.K + m.KK > 0 && m.I < (1 << 28) &&
+                       m.model != REC_MP && m.model != REC_TRANSREC_L1;
+    std::vector<int32_t> fallback; bool all_fallback = !fused;
+    if (fused) { if (int rc = topk_fused_impl(m, users_host, n_users, k, items_host, scores_host, st, fallback, &all_fallback)) return rc; }
+    if (!all_fallback && fallback.empty()) return 0;
+    // the score-matrix path: everything (f64 tables, k > 64, TransRec_L1, MostPopular, operands out of the f16 sweep's
+    // range) or the users whose lists the fused path gave up on
+    if (!users_host) {
+        all.resize(n_users);
+        HIP_TRY(hipMemcpy(all.data(), m.eval_users, sizeof(int32_t) * n_users, hipMemcpyDeviceToHost));
+        users_host = all.data();
+    }
+    std::vector<double> tmp_scores;
+    if (all_fallback) {
+        if (!scores_host) { tmp_scores.resize((size_t)n_users * 2 * k); scores_host = tmp_scores.data(); }
+        return precision == REC_F64 ? topk_impl<double>(m, users_host, n_users, k, items_host, scores_host, st)
+                                    : topk_impl<float>(m, users_host, n_users, k, items_host, scores_host, st);
+    }
+    std::vector<int32_t> fu(fallback.size()), fi(fallback.size() * 2 * k); std::vector<double> fs(fallback.size() * 2 * k);
+    for (size_t a = 0; a < fallback.size(); a++) fu[a] = users_host[fallback[a]];
+    if (int rc = topk_impl<float>(m, fu.data(), (int)fu.size(), k, fi.data(), fs.data(), st)) return rc;
+    for (size_t a = 0; a < fallback.size(); a++) {
+        memcpy(items_host + (size_t)fallback[a] * 2 * k, fi.data() + a * 2 * k, sizeof(int32_t) * 2 * k);
+        if (scores_host) memcpy(scores_host + (size_t)fallback[a] * 2 * k, fs.data() + a * 2 * k, sizeof(double) * 2 * k);
+    }
+    return 0;
 }
 
 int eval_run(const DevModel& m, int precision, int32_t* counts_host, double* xpos_host, hipStream_t st, double* score_ms,

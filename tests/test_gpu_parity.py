@@ -153,6 +153,93 @@ def test_topk_toy_all_models_and_short_lists(model):
     e.close()
 
 
+def _f32(W):
+    return None if W is None else np.asarray(W, np.float64).astype(np.float32).astype(np.float64)
+
+
+@pytest.mark.parametrize("tag", ML5_TAGS)
+def test_fused_top50_of_saved_model_match_oracle(tag):
+    """Criterion (b), second half, on the path that serves whole user populations: with f32 tables the lists come out of
+    the f16 sweep itself (running k-th best per query, survivors rescored in fp64; no score matrix).  Every user of the
+    reference-saved ML-5 model, both contexts, against the oracle's ranking of the same f32-rounded parameters, modulo
+    ties; HIT@50 of model.cpp:52-58 is membership of the positive in the list."""
+    g, model, co, ci, labels = fixture_case(tag, "ml5")
+    W = _f32(g["W_micro"].astype(np.float64) / 1e6)
+    e = make_engine(g, model, co, ci, labels, F32)
+    e.upload(W)
+    o = make_oracle(g, model, co, ci, labels)
+    valid = np.nonzero(np.asarray(g["counts"])[:, 2] >= 0)[0].astype(np.int32)
+    items, scores = e.eval_topk(len(valid), 50)            # users = NULL: everybody that has a test item
+    _, lists = e.kernel_stats(5)
+    assert lists == 2 * len(valid), (tag, lists)            # all of them through the fused sweep
+    _, counts, _ = e.eval()
+    rank = counts[valid, 2:3] - counts[valid, 0:2]          # [user][ctx]: candidates scored at least as high as the positive
+    pos = np.stack([o.val_item[valid], o.test_item[valid]], 1)
+    assert np.array_equal((items == pos[:, :, None]).any(2), rank < 50)
+    exact = 0
+    picked = valid[:: max(1, len(valid) // 96)][:96]
+    for u in picked:
+        a = int(np.searchsorted(valid, u))
+        for ctx in (0, 1):
+            exact += _check_topk(o.score_row(W, int(u), ctx), items[a, ctx], scores[a, ctx], 50)
+    assert exact >= 0.9 * 2 * len(picked)
+    # an explicit list of users gives the same lists, and so does the score-matrix path up to the order of ties
+    sub = valid[5:400:7]
+    i2, s2 = e.eval_topk(sub, 50)
+    assert np.array_equal(i2, items[5:400:7]) and np.array_equal(s2, scores[5:400:7])
+    e.set_option("topk_fused", 0)
+    try:
+        i3, s3 = e.eval_topk(sub, 50)
+        assert e.kernel_stats(5)[1] == 0
+    finally:
+        e.set_option("topk_fused", 1)
+    assert np.allclose(s3, s2, rtol=1e-9, atol=1e-12)
+    assert (i3 == i2).mean() > 0.99
+    e.close()
+
+
+@pytest.mark.parametrize("model", TOY_MODELS)
+def test_fused_topk_toy_all_models(model):
+    g, model, co, ci, labels = fixture_case(model, "toy")
+    W = _f32(g["W1"])
+    e = make_engine(g, model, co, ci, labels, F32)
+    e.upload(W)
+    o = make_oracle(g, model, co, ci, labels)
+    users = np.nonzero(np.asarray(g["counts"])[:, 2] >= 0)[0].astype(np.int32)
+    for k in (1, 7, 50, 64):
+        items, scores = e.eval_topk(users, k)
+        fused = e.kernel_stats(5)[1]
+        assert fused == (0 if model == "TransRec_L1" else 2 * len(users)), (model, k, fused)   # |.|_1 is not a contraction
+        for a, u in enumerate(users):
+            for ctx in (0, 1):
+                _check_topk(o.score_row(W, int(u), ctx), items[a, ctx], scores[a, ctx], k)
+    e.close()
+
+
+def test_fused_topk_hands_ties_it_cannot_hold_to_the_score_matrix():
+    """All-zero tables: every candidate ties with every other one, no list can hold them, and every user comes back from
+    the score-matrix path (lowest item ids first) - with trained item biases on top, the lists hold again."""
+    g, model, co, ci, labels = fixture_case("BPRMF", "ml5")
+    e = make_engine(g, model, co, ci, labels, F32)
+    W = np.zeros(e.nw)
+    e.upload(W)
+    o = make_oracle(g, model, co, ci, labels)
+    users = np.nonzero(np.asarray(g["counts"])[:, 2] >= 0)[0][:64].astype(np.int32)
+    items, scores = e.eval_topk(users, 50)
+    assert e.kernel_stats(5)[1] == 0
+    for a, u in enumerate(users):
+        for ctx in (0, 1):
+            assert _check_topk(o.score_row(W, int(u), ctx), items[a, ctx], scores[a, ctx], 50)   # ties in item order
+    W[:o.n_items] = np.linspace(-1, 1, o.n_items)    # beta
+    e.upload(W)
+    items, scores = e.eval_topk(users, 50)
+    assert e.kernel_stats(5)[1] == 2 * len(users)
+    for a, u in enumerate(users):
+        for ctx in (0, 1):
+            assert _check_topk(o.score_row(_f32(W), int(u), ctx), items[a, ctx], scores[a, ctx], 50)
+    e.close()
+
+
 @pytest.mark.parametrize("model", EVAL_MODELS)
 def test_sampled_eval_counts_match_oracle_on_the_same_draws(model):
     """rec_eval_sampled (the sampleAUC estimator on the device): for the item draws it reports, the per-user

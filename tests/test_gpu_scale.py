@@ -75,6 +75,40 @@ def test_full_shape_counts_of_sampled_users_match_oracle(big):
     assert 0.4 < m.auc_test < 0.6                       # random parameters
 
 
+def test_full_shape_top50_lists_match_oracle_and_the_counted_ranks(big):
+    """The ranking behind HIT@50 (model.cpp:32-58) at the full shape, after one epoch of training: the fused sweep's
+    top-50 lists of 512 sampled users against the restated ranking (modulo ties), and - for ALL 1M users, both contexts -
+    membership of the positive in its list against the rank the counting sweep gives it."""
+    from oracle import oracle_py as orc
+    from tests.test_gpu_parity import _check_topk
+    eng, seq_off, seq_item, test, val = big
+    W0 = eng.download()
+    eng.sgd_epoch(0.05, eng.steps_per_epoch, seed=17, epoch=0)
+    eng.sync()
+    W = eng.download()
+    users = np.linspace(0, U - 1, 512).astype(np.int32)
+    items, scores = eng.eval_topk(users, 50)
+    assert eng.kernel_stats(5)[1] == 2 * len(users)         # every list from the fused sweep
+    o = orc.Oracle("BPRMF", U, I, K, seq_off, seq_item, test, val, lam=0.01, bias_reg=0.01)
+    exact = 0
+    for a, u in enumerate(users):
+        for ctx in (0, 1):
+            exact += _check_topk(o.score_row(W, int(u), ctx), items[a, ctx], scores[a, ctx], 50)
+    assert exact >= 0.95 * 2 * len(users)
+    m, counts, _ = eng.eval()
+    n_all = int(m.n_users)
+    assert n_all == U                                         # every synthetic user has a test item: position = user id
+    all_items, _ = eng.eval_topk(n_all, 50, want_scores=False)
+    assert eng.kernel_stats(5)[1] == 2 * n_all
+    assert np.array_equal(all_items[users], items)
+    pos = np.stack([val, test], 1)
+    member = (all_items == pos[:, :, None]).any(2)
+    rank = counts[:, 2:3] - counts[:, 0:2]
+    assert np.array_equal(member, rank < 50)
+    assert abs(member[:, 1].mean() - m.hit_test) < 1e-12 and abs(member[:, 0].mean() - m.hit_val) < 1e-12
+    eng.upload(W0)
+
+
 def test_full_shape_sampler_support(big):
     eng, seq_off, seq_item, test, val = big
     T = eng.sample_tuples(1 << 20, seed=9, epoch=4)
@@ -132,6 +166,16 @@ def test_full_shape_other_models_replay_and_counts(corpus, model):
     assert _screen_held(eng) or model == "Fossil", model
     _, cref = o.eval(W1, nthreads=min(16, os.cpu_count() or 1))
     assert np.array_equal(counts[sample], cref[sample]), model
+    # top-50 lists of a few of them out of the fused sweep against the restated ranking (the restatement recomputes
+    # Fossil's history sum for every candidate, as the reference does: 8 users)
+    from tests.test_gpu_parity import _check_topk
+    few = sample[:: 64 if model == "Fossil" else 16].astype(np.int32)
+    items, scores = eng.eval_topk(few, 50)
+    fused = eng.kernel_stats(5)[1]
+    assert fused == 2 * len(few) or model == "Fossil", (model, fused)
+    for a, u in enumerate(few):
+        for ctx in (0, 1):
+            _check_topk(o.score_row(W1, int(u), ctx), items[a, ctx], scores[a, ctx], 50)
     eng.close()
 
 

@@ -140,3 +140,29 @@ def test_sharded_transrec_projects_the_combined_table_once(world):
     W = grp.gather_params()
     grp.close()
     assert np.isfinite(W).all() and abs(auc_p - ref) < 0.012, (auc_p, ref)
+
+
+def test_launches_only_add_gradient_steps_when_the_projection_is_switched_off():
+    """"project_after_launch" 0 (what sharded training sets): an update launch of TransRec must leave item rows that its
+    steps have pushed out of the unit ball where they are - the projection of TransRec.cpp:245-258 is then the caller's,
+    once, on the combined table.  With the option at 1 (the default) the same launch ends inside the ball."""
+    from oracle import oracle_py as orc
+    g, model, co, ci, labels = fixture_case("TransRec", "ml5")
+    seq_off, seq_item, test, val = orc.split(co, ci)
+    I = int(g["n_items"])
+    norms = {}
+    for opt in (1, 0):
+        e = ra.Engine("TransRec", I, seq_off, seq_item, test, val, K=10, lam=0.0, bias_reg=0.0, relation_reg=0.0, precision=F32)
+        e.set_option("project_after_launch", opt)
+        e.init_params(0)                       # rows start ON the unit ball (TransRec.cpp:14-30): any step outward leaves it
+        e.sgd_epoch(0.05, e.steps_per_epoch, seed=0, epoch=0)
+        e.sync()
+        W = e.download()
+        norms[opt] = np.linalg.norm(W[I:I + I * 10].reshape(I, 10), axis=1).max()
+        if opt == 0:
+            e.project_rows()
+            W = e.download()
+            assert np.linalg.norm(W[I:I + I * 10].reshape(I, 10), axis=1).max() <= 1.0 + 1e-5
+        e.close()
+    assert norms[1] <= 1.0 + 1e-5, norms
+    assert norms[0] > 1.0 + 1e-3, norms
