@@ -174,6 +174,10 @@ int rec_eval_sampled(rec_engine* e, int topn, int32_t n_sampled, uint64_t seed, 
  * list holds) the scores of a batch of users are written out [rows][n_items] in fp64 and selected from there. */
 int rec_eval_topk(rec_engine* e, const int32_t* users, int32_t n_users, int32_t k, int32_t* items_out, double* scores_out);
 
+/* users of this engine's range that model::AUC evaluates (those with a test item, model.cpp:22): what rec_metrics.n_users
+ * reports, without an evaluation */
+int64_t rec_eval_user_count(const rec_engine* e);
+
 /* Partial sums of rec_eval over this engine's users, for a sum all-reduce across ranks:
  * {sum AUC_val, AUC_test, HIT_val, HIT_test, MRR_val, MRR_test, sum AUC_test^2, n_users} */
 int rec_eval_sums(rec_engine* e, int topn, double sums[8]);

@@ -14,7 +14,7 @@ SEQUENTIAL, HOGWILD = 0, 1
 
 EXPORTS = ["rec_last_error", "rec_create", "rec_destroy", "rec_sync", "rec_nw", "rec_params_upload",
            "rec_params_download", "rec_params_read", "rec_params_init", "rec_snapshot_best", "rec_restore_best", "rec_sgd_replay", "rec_sgd_replay_static", "rec_partition_tuples", "rec_owner_slices",
-           "rec_sgd_epoch", "rec_sample_tuples", "rec_sample_events", "rec_tuples_drawn", "rec_steps_per_epoch", "rec_eval", "rec_eval_sampled", "rec_eval_sampled_per_user", "rec_eval_topk", "rec_eval_sums",
+           "rec_sgd_epoch", "rec_sample_tuples", "rec_sample_events", "rec_tuples_drawn", "rec_steps_per_epoch", "rec_eval", "rec_eval_sampled", "rec_eval_sampled_per_user", "rec_eval_topk", "rec_eval_user_count", "rec_eval_sums",
            "rec_device_count", "rec_shards_begin_round", "rec_shards_combine", "rec_project_rows", "rec_rebus_build_paths", "rec_fsub_mine", "rec_num_tables", "rec_table_info", "rec_set_option", "rec_kernel_stats"]
 
 
@@ -59,6 +59,8 @@ def lib():
         _lib.rec_tuples_drawn.restype = C.c_int64
         _lib.rec_tuples_drawn.argtypes = [C.c_void_p]
         _lib.rec_rebus_build_paths.restype = C.c_int64
+        _lib.rec_eval_user_count.restype = C.c_int64
+        _lib.rec_eval_user_count.argtypes = [C.c_void_p]
     return _lib
 
 
@@ -242,6 +244,10 @@ class Engine:
     def project_rows(self):
         """TransRec: every item row back onto the unit ball (what an update launch does unless "project_after_launch" is 0)."""
         _check(lib().rec_project_rows(self.handle))
+
+    @property
+    def n_eval_users(self):
+        return int(lib().rec_eval_user_count(self.handle))
 
     def eval_topk(self, users, k=50, want_scores=True):
         """users: an array of user ids, or an int n = the first n users that have a test item."""

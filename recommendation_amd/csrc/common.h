@@ -51,6 +51,7 @@ struct DevModel {
     const float* ev_alias_p;            // [n_ev]
     const int32_t* ev_alias_i;          // [n_ev] slot inside the item's range
     const int32_t* train_count;         // [I] occurrences of each item in the training sequences (MostPopular)
+    const int32_t* pop_order;           // [I] the items by descending train_count (ties by item id): the column order of the top-k sweep
     // [I+1] 0 = ordinary item, 1 = a "hot" item (see rec_set_option "hot_count"): its rows get plain stores where
     // the others get float atomics
     const uint8_t* hot;

@@ -301,6 +301,12 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     UP(elig, elig); UP(eval_users, eval_users);
     e->train_count_host = train_count;
     UP(train_count, train_count); UP(eta, eta);
+    {
+        std::vector<int32_t> pop_order(I);
+        for (int i = 0; i < I; i++) pop_order[i] = i;
+        std::stable_sort(pop_order.begin(), pop_order.end(), [&](int32_t a, int32_t b) { return train_count[a] > train_count[b]; });
+        UP(pop_order, pop_order);
+    }
     if (d->model == REC_MC) { UP(owner_rec, owner_rec); }
     else { UPR(owner_rec, (int64_t)ub * 16, (int64_t)(ue - ub) * 16, owner_rec); }
     if (d->model == REC_MC) { UP(succ_off, succ_off); UP(succ_item, succ_item); UP(sset_off, sset_off); UP(sset_item, sset_item); }
@@ -1029,6 +1035,8 @@ extern "C" int rec_eval_sums(rec_engine* e, int topn, double sums[8])
     reduce_metrics(e, counts.data(), topn, sums);
     return 0;
 }
+
+extern "C" int64_t rec_eval_user_count(const rec_engine* e) { return e ? e->dm.n_eval : -1; }
 
 extern "C" int rec_eval_topk(rec_engine* e, const int32_t* users, int32_t n_users, int32_t k, int32_t* items_out, double* scores_out)
 {

@@ -737,21 +737,24 @@ __device__ __forceinline__ void split16(float x, half_t& h, half_t& l)
 }
 
 // item planes Th, Tl [I_pad][KQ16] (zero beyond the tables' width and beyond the catalog) and the scaled constants
-// bs [I_pad] (+inf beyond the catalog: such a column is never counted and never within a margin)
+// bs [I_pad] (past_end beyond the catalog: +inf for the counting sweep - such a column is never counted and never within a
+// margin -, -inf for the top-k sweep, which lists what is NOT below its bar)
 __global__ void __launch_bounds__(256) screen16_items_kernel(EvalDev ev, const float* __restrict__ seg0, const float* __restrict__ seg1, int I, int I_pad,
                                                              int KQ16, const unsigned* __restrict__ bounds, half_t* __restrict__ Th, half_t* __restrict__ Tl,
-                                                             float* __restrict__ bs, int32_t* __restrict__ overflow)
+                                                             float* __restrict__ bs, int32_t* __restrict__ overflow, float past_end = INFINITY,
+                                                             const int32_t* __restrict__ order = nullptr)
 {
     const double sT = screen16_scale(bounds[2]), sq = screen16_scale(bounds[3]);
     const float sTf = (float)sT;
     const int64_t n = (int64_t)I_pad * KQ16;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t j = i / KQ16; const int k = (int)(i % KQ16);
+        const int64_t c = i / KQ16; const int k = (int)(i % KQ16);
+        const int64_t j = (order && c < I) ? order[c] : c;      // the item behind column c
         float x = 0.f;
-        if (j < I) { if (k < ev.K1) x = seg0[j * ev.K1 + k]; else if (k < ev.K1 + ev.K2) x = seg1[j * ev.K2 + (k - ev.K1)]; }
+        if (c < I) { if (k < ev.K1) x = seg0[j * ev.K1 + k]; else if (k < ev.K1 + ev.K2) x = seg1[j * ev.K2 + (k - ev.K1)]; }
         half_t h, l; split16(x * sTf, h, l);   // a power of two: the product is exact
         Th[i] = h; Tl[i] = l;
-        if (k == 0) bs[j] = j < I ? (float)(ev.bconst[j] * (sq * sT)) : INFINITY;
+        if (k == 0) bs[c] = c < I ? (float)(ev.bconst[j] * (sq * sT)) : past_end;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // the scaled constants must stay far from the end of f32's range
@@ -1819,6 +1822,7 @@ static int topk_impl(const DevModel& m0, const int32_t* users_host, int n_users,
 // A list that stays nearly full after a selection (more than TOPK_CAP - 16 columns within 2 M of the k-th best) marks
 // its query for the caller's fallback, the score-matrix path.
 #define TOPK_CAP 256
+#define TOPK_CLK 512            // click lists up to this length are searched in LDS
 #define TOPK_NEG_BIG (-3.0e38f)
 
 struct TopkDev {
@@ -1836,13 +1840,30 @@ struct TopkDev {
 __device__ __forceinline__ unsigned f32_key(unsigned b) { return (b >> 31) ? ~b : (b | 0x80000000u); }
 __device__ __forceinline__ unsigned f32_unkey(unsigned k) { return (k >> 31) ? (k & 0x7fffffffu) : ~k; }
 
+// v[i] for a per-lane index i: a select tree over the bits of i (N - 1 v_bfi_b32; registers cannot be indexed per lane, and
+// written as a conditional the compiler turns the pick into an indexed load from a copy of v in scratch memory)
+template <int N>
+__device__ __forceinline__ float pick_result(const float (&v)[N], int i)
+{
+    if constexpr (N == 1) return v[0];
+    else {
+        float h[N / 2];
+        const unsigned odd = 0u - (unsigned)(i & 1);
+#pragma unroll
+        for (int x = 0; x < N / 2; x++) h[x] = __uint_as_float((__float_as_uint(v[2 * x + 1]) & odd) | (__float_as_uint(v[2 * x]) & ~odd));
+        return pick_result<N / 2>(h, i >> 1);
+    }
+}
+
 __global__ void topk_meta_kernel(DevModel m, EvalDev ev, int4* __restrict__ qmeta)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ev.nq_pad) return;
     int4 r = make_int4(-1, -1, -1, 0);
     if (i < ev.nq) {
-        const int u = m.eval_users[i >> 1]; const int ctx = (int)(i & 1);
+        // one query per (user, context); or one per user when both contexts have the same query vector (BPRMF): then the
+        // validation positive is y and the test positive z, and neither is a candidate of either list
+        const int u = m.eval_users[ev.nctx == 2 ? i >> 1 : i]; const int ctx = ev.nctx == 2 ? (int)(i & 1) : 0;
         const int val = m.val_item[u], test = m.test_item[u];
         r = make_int4(u, ctx ? test : val, ctx ? val : test, 0);
     }
@@ -1881,7 +1902,7 @@ __global__ void __launch_bounds__(256) topk16_queries_kernel(EvalDev ev, int KQ1
 
 template <int KQ>
 __global__ void __launch_bounds__(256, 2) topk_sweep16_kernel(EvalDev ev, TopkDev tk, const int64_t* __restrict__ clk_off, const int32_t* __restrict__ clk_item,
-                                                              const half_t* __restrict__ Th, const half_t* __restrict__ Tl, const float* __restrict__ bs,
+                                                              const int32_t* __restrict__ col_item, const half_t* __restrict__ Th, const half_t* __restrict__ Tl, const float* __restrict__ bs,
                                                               const half_t* __restrict__ Qh, const half_t* __restrict__ Ql, int I)
 {
     constexpr int MT = Screen16Shape<KQ, false>::MT, NI = Screen16Shape<KQ, false>::NI, QB = Screen16Shape<KQ, false>::QB;
@@ -1892,6 +1913,7 @@ __global__ void __launch_bounds__(256, 2) topk_sweep16_kernel(EvalDev ev, TopkDe
     half_t* const tile_l = tiles + NI * STR;
     __shared__ float tile_b[NI];
     __shared__ int q_cnt[QB];                 // entries in each query's list (this block's range)
+    __shared__ int clk_lds[4][TOPK_CLK];      // per wavefront: the click list of the user whose list is being selected from
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, quad = lane >> 4;
     const int64_t qblock = (int64_t)blockIdx.x * QB;
@@ -1941,6 +1963,11 @@ __global__ void __launch_bounds__(256, 2) topk_sweep16_kernel(EvalDev ev, TopkDe
         const int n = min(q_cnt[qi], TOPK_CAP);
         const int4 meta = tk.qmeta[qg];
         const int32_t* clk = clk_item + clk_off[meta.x]; const int nc = (int)(clk_off[meta.x + 1] - clk_off[meta.x]);
+        // the user's (sorted) click list goes through LDS when it fits: the membership searches below are chains of
+        // dependent loads, and from memory they made a selection cost 20 us - during which the block's other wavefronts
+        // wait at the next tile barrier
+        const bool cached = nc <= TOPK_CLK;
+        if (cached) for (int i = lane; i < nc; i += 64) clk_lds[wave][i] = clk[i];
         __threadfence();                       // the appends of this wavefront have reached memory
         unsigned long long ent[TOPK_CAP / 64]; unsigned key[TOPK_CAP / 64];
 #pragma unroll
@@ -1948,8 +1975,12 @@ __global__ void __launch_bounds__(256, 2) topk_sweep16_kernel(EvalDev ev, TopkDe
             const int idx = lane + 64 * i;
             // a load that does not stop at this compute unit's vector cache (which may hold the line as an earlier selection read it)
             ent[i] = idx < n ? __hip_atomic_load(base + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffull;
+        }
+#pragma unroll
+        for (int i = 0; i < TOPK_CAP / 64; i++) {
+            const int idx = lane + 64 * i;
             const int item = (int)(ent[i] >> 32);
-            const bool ok = idx < n && item != meta.y && item != meta.z && !sorted_contains(clk, nc, item);
+            const bool ok = idx < n && item != meta.y && item != meta.z && !(cached ? sorted_contains(clk_lds[wave], nc, item) : sorted_contains(clk, nc, item));
             key[i] = ok ? f32_key((unsigned)ent[i]) : 0u;
         }
         unsigned prefix = 0;                   // the largest v with at least k keys >= v (0: fewer than k valid entries)
@@ -2012,7 +2043,7 @@ __global__ void __launch_bounds__(256, 2) topk_sweep16_kernel(EvalDev ev, TopkDe
 #pragma unroll 1
         for (int sub = 0; sub < NI / 16; sub++) {
             const int j = item0 + sub * 16 + col;
-            float sc[MT][4];
+            float sc[MT * 4];
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
                 float4_t am = (float4_t){0.f, 0.f, 0.f, 0.f};
@@ -2024,36 +2055,40 @@ __global__ void __launch_bounds__(256, 2) topk_sweep16_kernel(EvalDev ev, TopkDe
 #pragma unroll
                 for (int ch = 0; ch < NCH; ch++) am = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt][ch], bh[ch], am, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 4; r++) sc[mt][r] = am[r] + bj;
+                for (int r = 0; r < 4; r++) sc[4 * mt + r] = am[r] + bj;
             }
             if (sub + 1 < NI / 16) read_frags(sub + 1);
-            // y = score - bar: non-negative and finite <=> listed (a column past the end of the catalog scores +inf; a
-            // padding row's bar is +inf).  As unsigned integers those patterns are the ones <= 0x7f7fffff.
-            unsigned mn = 0xffffffffu;
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) {
-#pragma unroll
-                for (int r = 0; r < 4; r += 2) {
-                    const unsigned y0 = __float_as_uint(sc[mt][r] - bar[mt][r]), y1 = __float_as_uint(sc[mt][r + 1] - bar[mt][r + 1]);
-                    mn = min(min(mn, y0), y1);   // one v_min3_u32
-                }
-            }
-            if (!__ballot(mn <= 0x7f7fffffu)) continue;
-            bool full = false;
+            // y = score - bar: a column is listed when y is not negative.  The sign bits of a sub-step's MT * 4 results are
+            // shifted into one register (v_alignbit: result i of the sub-step ends up at bit MT * 4 - 1 - i), so that the
+            // rare sub-step that lists something has its mask at hand.  (A column past the end of the catalog scores -inf,
+            // a padding row's bar is +inf: both give y = -inf.  NaN never gets here: the launcher checks the operands.)
+            unsigned sg = 0;
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const bool in = __float_as_uint(sc[mt][r] - bar[mt][r]) <= 0x7f7fffffu;
-                    if (!__ballot(in)) continue;
-                    if (in) {
-                        const int qi = qw + mt * 16 + 4 * quad + r;
-                        const int at = atomicAdd(&q_cnt[qi], 1);
-                        if (at < TOPK_CAP)
-                            tk.cand[((qblock + qi) * tk.ranges + blockIdx.y) * TOPK_CAP + at] = ((unsigned long long)(unsigned)j << 32) | __float_as_uint(sc[mt][r]);
-                        full |= at + 1 > TOPK_CAP - 16;   // a sub-step adds at most 16 columns to a list: selected before the next one
-                    }
+                for (int r = 0; r < 4; r++) sg = __builtin_amdgcn_alignbit(sg, __float_as_uint(sc[4 * mt + r] - bar[mt][r]), 31);
+            constexpr unsigned ALL = (1u << (MT * 4)) - 1u;
+            const unsigned open = ~sg & ALL;
+            if (!__ballot(open != 0u)) continue;
+            // Every lane walks its own set bits; an iteration serves the first open result of ALL lanes with one LDS
+            // atomic, one wait and one store (typically a handful of lanes hold one bit each: one iteration).  The result
+            // a lane's bit names is picked out of its registers by a select tree over the bits of the index (a loop over
+            // the MT * 4 results with a scalar skip paid an LDS round trip per result instead of per iteration).
+            bool full = false;
+            unsigned todo = open;
+            while (__ballot(todo != 0u)) {
+                if (todo) {
+                    const int b = 31 - __clz((int)todo);
+                    todo &= ~(1u << b);
+                    const int i = MT * 4 - 1 - b;                 // result 4 mt + r
+                    const float v = pick_result<MT * 4>(sc, i);
+                    const int qi = qw + (i >> 2) * 16 + 4 * quad + (i & 3);
+                    const int at = atomicAdd(&q_cnt[qi], 1);
+                    if (at < TOPK_CAP)
+                        tk.cand[((qblock + qi) * tk.ranges + blockIdx.y) * TOPK_CAP + at] = ((unsigned long long)(unsigned)col_item[j] << 32) | __float_as_uint(v);
+                    full |= at + 1 > TOPK_CAP - 16;   // a sub-step adds at most 16 columns to a list: selected before the next one
                 }
+            }
             if (!__ballot(full)) continue;
             unsigned long long need = __ballot(lane < MT * 16 && q_cnt[qw + (lane < MT * 16 ? lane : 0)] > TOPK_CAP - 16);
             while (need) {
@@ -2087,61 +2122,103 @@ __global__ void __launch_bounds__(256) topk_finish_kernel(DevModel m, EvalDev ev
     const int w = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (w >= ev.nq) return;
     const int k = tk.k;
-    int32_t* items = tk.items_out + (int64_t)w * k;
-    double* scores = tk.scores_out + (int64_t)w * k;
+    // a query yields one list, or two (validation, test) when both contexts share it
+    const int nlists = ev.nctx == 1 ? 2 : 1;
+    const int64_t row0 = ev.nctx == 1 ? 2 * (int64_t)w : w;
     const int4 meta = tk.qmeta[w];
     const int32_t* clk = m.clk_item + m.clk_off[meta.x]; const int nc = (int)(m.clk_off[meta.x + 1] - m.clk_off[meta.x]);
     unsigned long long* lists = tk.cand + (int64_t)w * tk.ranges * TOPK_CAP;
     const int32_t* cnts = tk.cand_cnt + (int64_t)w * tk.ranges;
     bool over = tk.q_over[w] != 0;
-    // entries that are not candidates get the pattern of key 0
-    for (int r = 0; r < tk.ranges; r++) {
-        const int n = cnts[r];
-        for (int idx = lane; idx < n; idx += 64) {
-            const unsigned long long e = lists[r * TOPK_CAP + idx];
-            const int item = (int)(e >> 32);
-            if (item == meta.y || item == meta.z || sorted_contains(clk, nc, item)) lists[r * TOPK_CAP + idx] = e | 0xffffffffull;
+    float nb = TOPK_NEG_BIG;
+    int ns = 0;
+    const float mq = ev.qmar[w];
+    if (tk.ranges == 1 && !over) {
+        // one list: its entries stay in registers (four per lane) from the membership test to the compaction
+        __shared__ int clk_lds[4][TOPK_CLK];
+        const int n = cnts[0];
+        const bool cached = nc <= TOPK_CLK;
+        if (cached) for (int i = lane; i < nc; i += 64) clk_lds[wv][i] = clk[i];
+        unsigned long long ent[TOPK_CAP / 64]; unsigned key[TOPK_CAP / 64];
+#pragma unroll
+        for (int i = 0; i < TOPK_CAP / 64; i++) { const int idx = lane + 64 * i; ent[i] = idx < n ? lists[idx] : 0xffffffffull; }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < TOPK_CAP / 64; i++) {
+            const int idx = lane + 64 * i;
+            const int item = (int)(ent[i] >> 32);
+            const bool ok = idx < n && item != meta.y && item != meta.z && !(cached ? sorted_contains(clk_lds[wv], nc, item) : sorted_contains(clk, nc, item));
+            key[i] = ok ? f32_key((unsigned)ent[i]) : 0u;
         }
-    }
-    __threadfence();
-    unsigned prefix = 0;
+        unsigned prefix = 0;
 #pragma unroll 1
-    for (int bit = 31; bit >= 0 && !over; bit--) {
-        const unsigned v = prefix | (1u << bit);
-        int c = 0;
+        for (int bit = 31; bit >= 0; bit--) {
+            const unsigned v = prefix | (1u << bit);
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < TOPK_CAP / 64; i++) c += __popcll(__ballot(key[i] >= v));
+            if (c >= k) prefix = v;
+        }
+        if (prefix) {
+            const float tau = __uint_as_float(f32_unkey(prefix));
+            nb = (tau - 2.f * mq) - 2.4e-7f * (fabsf(tau) + 2.f * mq);
+        }
+#pragma unroll
+        for (int i = 0; i < TOPK_CAP / 64; i++) {
+            const bool keep = key[i] != 0u && __uint_as_float((unsigned)ent[i]) >= nb;
+            const unsigned long long bal = __ballot(keep);
+            const int at = ns + __popcll(bal & ((1ull << lane) - 1ull));
+            if (keep && at < TOPK_SURV - 1) s_item[wv][at] = (int)(ent[i] >> 32);
+            ns += __popcll(bal);
+        }
+    } else if (!over) {
+        // entries that are not candidates get the pattern of key 0
+        for (int r = 0; r < tk.ranges; r++) {
+            const int n = cnts[r];
+            for (int idx = lane; idx < n; idx += 64) {
+                const unsigned long long e = lists[r * TOPK_CAP + idx];
+                const int item = (int)(e >> 32);
+                if (item == meta.y || item == meta.z || sorted_contains(clk, nc, item)) lists[r * TOPK_CAP + idx] = e | 0xffffffffull;
+            }
+        }
+        __threadfence();
+        unsigned prefix = 0;
+#pragma unroll 1
+        for (int bit = 31; bit >= 0; bit--) {
+            const unsigned v = prefix | (1u << bit);
+            int c = 0;
+            for (int r = 0; r < tk.ranges; r++) {
+                const int n = cnts[r];
+                for (int i0 = 0; i0 < n; i0 += 64) {
+                    const int idx = i0 + lane;
+                    const unsigned key = idx < n ? f32_key((unsigned)__hip_atomic_load(lists + r * TOPK_CAP + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0u;
+                    c += __popcll(__ballot(key >= v));
+                }
+            }
+            if (c >= k) prefix = v;
+        }
+        if (prefix) {
+            const float tau = __uint_as_float(f32_unkey(prefix));
+            nb = (tau - 2.f * mq) - 2.4e-7f * (fabsf(tau) + 2.f * mq);
+        }
         for (int r = 0; r < tk.ranges; r++) {
             const int n = cnts[r];
             for (int i0 = 0; i0 < n; i0 += 64) {
                 const int idx = i0 + lane;
-                const unsigned key = idx < n ? f32_key((unsigned)__hip_atomic_load(lists + r * TOPK_CAP + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0u;
-                c += __popcll(__ballot(key >= v));
+                const unsigned long long e = idx < n ? __hip_atomic_load(lists + r * TOPK_CAP + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffull;
+                const bool keep = f32_key((unsigned)e) != 0u && __uint_as_float((unsigned)e) >= nb;
+                const unsigned long long bal = __ballot(keep);
+                const int at = ns + __popcll(bal & ((1ull << lane) - 1ull));
+                if (keep && at < TOPK_SURV - 1) s_item[wv][at] = (int)(e >> 32);
+                ns += __popcll(bal);
             }
-        }
-        if (c >= k) prefix = v;
-    }
-    float nb = TOPK_NEG_BIG;
-    if (prefix) {
-        const float tau = __uint_as_float(f32_unkey(prefix)), mq = ev.qmar[w];
-        nb = (tau - 2.f * mq) - 2.4e-7f * (fabsf(tau) + 2.f * mq);
-    }
-    int ns = 0;
-    for (int r = 0; r < tk.ranges && !over; r++) {
-        const int n = cnts[r];
-        for (int i0 = 0; i0 < n; i0 += 64) {
-            const int idx = i0 + lane;
-            const unsigned long long e = idx < n ? __hip_atomic_load(lists + r * TOPK_CAP + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffull;
-            const bool keep = f32_key((unsigned)e) != 0u && __uint_as_float((unsigned)e) >= nb;
-            const unsigned long long bal = __ballot(keep);
-            const int at = ns + __popcll(bal & ((1ull << lane) - 1ull));
-            if (keep && at < TOPK_SURV - 1) s_item[wv][at] = (int)(e >> 32);
-            ns += __popcll(bal);
         }
     }
     if (ns > TOPK_SURV - 1) over = true;
     if (over) {
         // left to the caller's fallback
         if (lane == 0) tk.q_over[w] = 1;
-        for (int r = lane; r < k; r += 64) { items[r] = -1; scores[r] = -INFINITY; }
+        for (int r = lane; r < nlists * k; r += 64) { tk.items_out[row0 * k + r] = -1; tk.scores_out[row0 * k + r] = -INFINITY; }
         return;
     }
     const double* q = ev.Q + (int64_t)w * ev.KQ;
@@ -2157,17 +2234,24 @@ __global__ void __launch_bounds__(256) topk_finish_kernel(DevModel m, EvalDev ev
         s = group_sum<16>(s) + ev.bconst[ec];
         if (l16 == 0 && idx < ns) s_score[wv][idx] = s;
     }
-    if (lane == 0) { s_item[wv][ns] = meta.y; s_score[wv][ns] = ev.thr[w]; }
     const int nt = ns + 1;
     const double aq = ev.aq[w];
-    // LDS writes of this wavefront are visible to its later reads (in order); rank by counting
-    for (int i = lane; i < nt; i += 64) {
-        const double si = s_score[wv][i]; const int ii = s_item[wv][i];
-        int rank = 0;
-        for (int x = 0; x < nt; x++) { const double sx = s_score[wv][x]; rank += (sx > si || (sx == si && s_item[wv][x] < ii)) ? 1 : 0; }
-        if (rank < k) { items[rank] = ii; scores[rank] = si + aq; }
+    for (int li = 0; li < nlists; li++) {
+        int32_t* items = tk.items_out + (row0 + li) * k;
+        double* scores = tk.scores_out + (row0 + li) * k;
+        // the list's positive joins the survivors with the score the reference formula gives it
+        if (lane == 0) { s_item[wv][ns] = li ? meta.z : meta.y; s_score[wv][ns] = li ? ev.thr2[w] : ev.thr[w]; }
+        __builtin_amdgcn_wave_barrier();
+        // LDS writes of this wavefront are visible to its later reads (in order); rank by counting
+        for (int i = lane; i < nt; i += 64) {
+            const double si = s_score[wv][i]; const int ii = s_item[wv][i];
+            int rank = 0;
+            for (int x = 0; x < nt; x++) { const double sx = s_score[wv][x]; rank += (sx > si || (sx == si && s_item[wv][x] < ii)) ? 1 : 0; }
+            if (rank < k) { items[rank] = ii; scores[rank] = si + aq; }
+        }
+        for (int r = nt + lane; r < k; r += 64) { items[r] = -1; scores[r] = -INFINITY; }
+        __builtin_amdgcn_wave_barrier();
     }
-    for (int r = nt + lane; r < k; r += 64) { items[r] = -1; scores[r] = -INFINITY; }
 }
 
 static int g_topk_fused = 1;
@@ -2180,7 +2264,7 @@ static void launch_topk_sweep(const EvalDev& ev, const TopkDev& tk, const DevMod
                               const half_t* Ql, hipStream_t st)
 {
     const unsigned blocks = (unsigned)(ev.nq_pad / Screen16Shape<KQ, false>::QB);
-    hipLaunchKernelGGL((topk_sweep16_kernel<KQ>), dim3(blocks, ev.ranges), dim3(256), 0, st, ev, tk, m.clk_off, m.clk_item, Th, Tl, bs, Qh, Ql, m.I);
+    hipLaunchKernelGGL((topk_sweep16_kernel<KQ>), dim3(blocks, ev.ranges), dim3(256), 0, st, ev, tk, m.clk_off, m.clk_item, m.pop_order, Th, Tl, bs, Qh, Ql, m.I);
 }
 
 // users_host == nullptr: the first n_users users of m.eval_users.  fallback: positions (in users order) whose lists the
@@ -2193,7 +2277,10 @@ static int topk_fused_impl(const DevModel& m0, const int32_t* users_host, int n_
     const int I = m.I;
     *all_fallback = false;
     EvalDev ev = {};
-    ev.nctx = 2; ev.force2 = 1;
+    // BPRMF's prediction ignores the previous item (BPRMF.cpp:69-72): both contexts of a user share one query, and one
+    // sweep serves both lists
+    ev.nctx = m.model == REC_BPRMF ? 1 : 2; ev.force2 = 1;
+    const int nctx = ev.nctx;
     ev.seg0 = ev.seg1 = -1; ev.K1 = ev.K2 = 0;
     switch (m.model) {
     case REC_BPRMF: ev.seg0 = BPRMF_GI; ev.K1 = m.K; break;
@@ -2213,8 +2300,8 @@ static int topk_fused_impl(const DevModel& m0, const int32_t* users_host, int n_
     const int QBLK = screen16_qb(KQ16, false);
     const int NI16 = KQ16 <= 128 ? 64 : 32;
     const int I_pad = ((I + NI16 - 1) / NI16) * NI16;
-    const int batch_users = std::min(n_users, 1 << 19);
-    const int max_rows = ((2 * batch_users + QBLK - 1) / QBLK) * QBLK;
+    const int batch_users = std::min(n_users, (1 << 20) / nctx);
+    const int max_rows = ((nctx * batch_users + QBLK - 1) / QBLK) * QBLK;
     // catalog ranges: enough blocks to fill the chip when the queries alone do not (a short list of users)
     int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     {
@@ -2245,8 +2332,8 @@ static int topk_fused_impl(const DevModel& m0, const int32_t* users_host, int n_
     TF_TRY(alloc((void**)&tk.cand, sizeof(unsigned long long) * (size_t)max_rows * ev.ranges * TOPK_CAP));
     TF_TRY(alloc((void**)&tk.cand_cnt, sizeof(int32_t) * (size_t)max_rows * ev.ranges));
     TF_TRY(alloc((void**)&tk.q_over, sizeof(int32_t) * max_rows));
-    TF_TRY(alloc((void**)&tk.items_out, sizeof(int32_t) * (size_t)max_rows * k));
-    TF_TRY(alloc((void**)&tk.scores_out, sizeof(double) * (size_t)max_rows * k));
+    TF_TRY(alloc((void**)&tk.items_out, sizeof(int32_t) * (size_t)batch_users * 2 * k));
+    TF_TRY(alloc((void**)&tk.scores_out, sizeof(double) * (size_t)batch_users * 2 * k));
     TF_TRY(alloc((void**)&over, sizeof(int32_t)));
     TF_TRY(alloc((void**)&b4, sizeof(unsigned) * 4));
     TF_TRY(alloc((void**)&Th, sizeof(half_t) * (size_t)I_pad * KQ16));
@@ -2269,7 +2356,7 @@ static int topk_fused_impl(const DevModel& m0, const int32_t* users_host, int n_
         if (users_host) { TF_TRY(hipMemcpyAsync(d_users, users_host + u0, sizeof(int32_t) * nu, hipMemcpyHostToDevice, st)); m.eval_users = d_users; }
         else m.eval_users = all_users + u0;
         m.n_eval = nu;
-        ev.nq = 2 * nu; ev.nq_pad = ((ev.nq + QBLK - 1) / QBLK) * QBLK;
+        ev.nq = nctx * nu; ev.nq_pad = ((ev.nq + QBLK - 1) / QBLK) * QBLK;
         TF_TRY(hipEventRecord(e0, st));
         TF_TRY(hipMemsetAsync(ev.Q, 0, sizeof(double) * (size_t)ev.nq_pad * ev.KQ, st));
         TF_TRY(hipMemsetAsync(tk.q_over, 0, sizeof(int32_t) * ev.nq_pad, st));
@@ -2278,7 +2365,7 @@ static int topk_fused_impl(const DevModel& m0, const int32_t* users_host, int n_
         hipLaunchKernelGGL(topk_meta_kernel, dim3((ev.nq_pad + 255) / 256), dim3(256), 0, st, m, ev, qmeta);
         hipLaunchKernelGGL(build_queries_kernel<T>, dim3(blocks_for_waves(ev.nq)), dim3(256), 0, st, m, ev);
         hipLaunchKernelGGL(screen16_bounds_kernel, dim3(1024), dim3(256), 0, st, ev, seg0, seg1, I, b4);
-        hipLaunchKernelGGL(screen16_items_kernel, dim3(2048), dim3(256), 0, st, ev, seg0, seg1, I, I_pad, KQ16, (const unsigned*)b4, Th, Tl, bs, over);
+        hipLaunchKernelGGL(screen16_items_kernel, dim3(2048), dim3(256), 0, st, ev, seg0, seg1, I, I_pad, KQ16, (const unsigned*)b4, Th, Tl, bs, over, -INFINITY, m.pop_order);
         hipLaunchKernelGGL(topk16_queries_kernel, dim3(blocks_for_waves(ev.nq_pad)), dim3(256), 0, st, ev, KQ16, (const unsigned*)b4, Qh, Ql, over);
         switch (KQ16) {
         case 32: launch_topk_sweep<32>(ev, tk, m, Th, Tl, bs, Qh, Ql, st); break;
@@ -2293,8 +2380,8 @@ static int topk_fused_impl(const DevModel& m0, const int32_t* users_host, int n_
         over_host.resize(ev.nq);
         TF_TRY(hipMemcpyAsync(&ov, over, sizeof ov, hipMemcpyDeviceToHost, st));
         TF_TRY(hipMemcpyAsync(over_host.data(), tk.q_over, sizeof(int32_t) * ev.nq, hipMemcpyDeviceToHost, st));
-        TF_TRY(hipMemcpyAsync(items_host + (size_t)u0 * 2 * k, tk.items_out, sizeof(int32_t) * (size_t)ev.nq * k, hipMemcpyDeviceToHost, st));
-        if (scores_host) TF_TRY(hipMemcpyAsync(scores_host + (size_t)u0 * 2 * k, tk.scores_out, sizeof(double) * (size_t)ev.nq * k, hipMemcpyDeviceToHost, st));
+        TF_TRY(hipMemcpyAsync(items_host + (size_t)u0 * 2 * k, tk.items_out, sizeof(int32_t) * (size_t)nu * 2 * k, hipMemcpyDeviceToHost, st));
+        if (scores_host) TF_TRY(hipMemcpyAsync(scores_host + (size_t)u0 * 2 * k, tk.scores_out, sizeof(double) * (size_t)nu * 2 * k, hipMemcpyDeviceToHost, st));
         TF_TRY(hipStreamSynchronize(st));
         float ms = 0; TF_TRY(hipEventElapsedTime(&ms, e0, e1)); g_topk_fused_ms += ms;
         if (ov) {   // tables or queries that are not finite, or out of the f16 sweep's range
@@ -2304,7 +2391,7 @@ static int topk_fused_impl(const DevModel& m0, const int32_t* users_host, int n_
             return 0;
         }
         for (int a = 0; a < nu; a++) {
-            if (over_host[2 * a] || over_host[2 * a + 1]) fallback.push_back(u0 + a);
+            if (over_host[nctx * a] || over_host[nctx * a + nctx - 1]) fallback.push_back(u0 + a);
             else g_topk_fused_lists += 2;
         }
     }
