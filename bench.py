@@ -188,6 +188,7 @@ def main():
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--group", type=int, default=-1, help="group_by_item: 0 off, 1 run-combining kernel only, 2 event-major sampling (chunks grouped by positive item); -1 = engine default")
     ap.add_argument("--policy", type=int, default=-1, help="update_policy: 0 exact atomics, 1 hybrid, 2 plain stores; -1 = engine default")
+    ap.add_argument("--hot-count", type=int, default=-1, help="hot_count: items with at least this many training occurrences get plain stores under the hybrid policy; -1 = engine default")
     ap.add_argument("--chunk", type=int, default=1 << 27)
     ap.add_argument("--overlap", type=int, default=0)
     ap.add_argument("--share-positive", type=int, default=0, help="share_positive of the group models (1, 2); 0 = engine default")
@@ -276,6 +277,8 @@ def main():
             "neg_share": 1, "pos_share": 1, "group": 0}
     if args.policy >= 0:
         eng.set_option("update_policy", args.policy); mode["policy"] = args.policy
+    if args.hot_count >= 0:
+        eng.set_option("hot_count", args.hot_count)
     if args.group >= 0:
         eng.set_option("group_by_item", args.group); mode["group"] = args.group
     eng.set_option("chunk", args.chunk)

@@ -13,14 +13,13 @@ sits 0.003 .. 0.0047 below the reference there for BPRMF / FPMC / PRME on a corp
 times what the chip holds in flight; 0.0051 has been seen), HIT@50 within max(0.006, range of the reference's seeds for the
 same mean).
 
-The history models are held to these bounds from below and to 0.015 from above: with the hybrid scatter (plain stores
-on user rows, biases and the hot items' rows) they end slightly ABOVE the reference on this corpus - Fossil /
-FossilSimple peak after 3-4 epochs and then overfit, and the updates a plain store loses on the most clicked rows
-slow that down (measured, means of 2 seeds against 3 reference seeds: Fossil best test AUC 0.7491 against 0.7459,
-trajectory HIT@50 0.2235 against 0.2184, HIT@50 at the best checkpoint up to 0.2371 against 0.2235 from run to run; REBUS best
-test AUC 0.7621 against 0.7567) - while with atomics on every row
-("update_policy" 0) they sit on the reference (REBUS 0.7560 / 0.7567) or just below it in the trajectory mean (Fossil
-0.7293 / 0.7348).  Pairs of tuples per history walk ("user_batch" 2) move neither by more than 0.002.
+The history models (Fossil, FossilSimple, REBUS) run here with what rec_create selects for a corpus of this size - float
+atomics on every row, one tuple per history walk - and are held to the same two-sided bounds (measured: Fossil best test AUC
+0.7438 against 0.7459, REBUS 0.7572 against 0.7567).  Their large-corpus defaults (hybrid scatter, pairs of tuples per walk)
+are checked where they switch on by themselves, against the sequential restatement on a 5.9M-step corpus:
+tests/test_gpu_seq_anchor.py.  Forced onto this corpus - where "items holding >= 1/1024 of the positives" are 5 % of the catalog
+and a third of all history positions, not 28 items of 200 000 - they end above the reference (REBUS best test AUC 0.7622
+against 0.7567): that is no regime the engine selects, and it is not tested.
 Needs an MI355X."""
 import json
 import os
@@ -35,14 +34,13 @@ pytestmark = pytest.mark.gpu
 
 REF = json.load(open(os.path.join(GOLD, "mid_trajectories.json")))
 
-GROUP = ["BPRMF", "MC", "FPMC", "PRME", "HRM_avg", "TransRec"]
+GROUP = ["BPRMF", "MC", "FPMC", "PRME", "HRM_avg", "TransRec"]   # their large-corpus default forced here: test_large_corpus_defaults_follow_the_reference
 HISTORY = ["Fossil", "FossilSimple", "REBUS"]
 # what rec_create turns on at >= 4M steps per epoch, forced here on 575k steps per epoch
 LARGE_DEFAULTS = [("update_policy", 1)]
 # option: launches of at most 2 tuples per item (8000 tuples here), partitioned by the negative's slice of the catalog
 OWNER = [("update_policy", 1), ("owner_neg", 1), ("owner_min", 1), ("owner_per_item", 2)]
 SHARED_NEGATIVES = [("update_policy", 1), ("owner_neg", 0), ("share_negative", 2)]
-HISTORY_PAIRS = [("update_policy", 1), ("user_batch", 2)]
 
 
 def _tail_means(traj):
@@ -54,13 +52,13 @@ def _within(x, ref, below, above):
     return -below <= x - ref <= above
 
 
-def _check(model, options, hit_slack=0.0, above=0.01, traj_auc_slack=0.0, auc_slack=0.0):
-    """above: how far the engine may end above the reference.  The bounds of the module's docstring hold from below; ending
-    above the reference is allowed up to 0.01 (0.015 for the history models): HRM_avg, whose reference runs peak anywhere
-    between epoch 16 and 38, has come out 0.0056 above in test AUC with pairs sharing their negative."""
+def _check(model, options, hit_slack=0.0, above=0.0, traj_auc_slack=0.0, auc_slack=0.0, seeds=(0, 1)):
+    """The bounds of the module's docstring, two-sided.  above > 0 (options only, never a default): how far an option
+    may end above the reference - HRM_avg, whose reference runs peak anywhere between epoch 16 and 38, has come out 0.0056
+    above in test AUC with pairs sharing their negative."""
     ref = [r for r in REF if r["model"] == model]
     assert len(ref) == 3
-    got = [best_of_trajectory_mid(ref[0], options, seed=s) for s in (0, 1)]
+    got = [best_of_trajectory_mid(ref[0], options, seed=s) for s in seeds]
     auc_ref = np.mean([r["auc_test_at_best"] for r in ref]); hit_ref = [r["hit50_test_at_best"] for r in ref]
     auc = np.mean([g["auc_test_at_best"] for g in got]); hit = np.mean([g["hit50_test_at_best"] for g in got])
     val = np.mean([g["best_auc_val"] for g in got]); val_ref = np.mean([r["best_auc_val"] for r in ref])
@@ -87,33 +85,30 @@ def test_large_corpus_defaults_follow_the_reference(model):
 
 
 @pytest.mark.parametrize("model", ["BPRMF", "FPMC", "HRM_avg"])
-def test_owner_mode_with_short_launches_follows_the_reference(model):
-    """An option, not the default: its steps in the negative's role reach memory late and out of order, which costs
-    accuracy in proportion to the launch length (FPMC here, 2 tuples per item and launch: trajectory-mean test AUC 0.7164
-    against 0.7214) - hence the 0.003 of extra room below."""
-    _check(model, OWNER, hit_slack=0.003, traj_auc_slack=0.003)
+def test_owner_mode_with_short_launches_stays_close_to_the_reference(model):
+    """An option, not the default, and not claimed to meet the bounds: its steps in the negative's role reach memory late
+    and out of order, which costs accuracy in proportion to the launch length (FPMC here, 2 tuples per item and launch:
+    trajectory-mean test AUC 0.7164 against 0.7214) - held to the bounds plus 0.003."""
+    _check(model, OWNER, hit_slack=0.003, traj_auc_slack=0.003, above=0.01)
 
 
 @pytest.mark.parametrize("model", ["BPRMF", "MC", "FPMC", "PRME", "HRM_avg"])
-def test_shared_negatives_follow_the_reference(model):
-    """An option, not the default: AUC follows the reference to 0.0065 at the best checkpoint (the option costs 0.002-0.003
-    of test AUC while training is young, and FPMC's two seeds have come out 0.00503 below the reference's three, best
-    iterations 34 / 38 against 40 / 40 / 40); HIT@50 is allowed the 0.015 this option was measured to cost at the top of the
-    ranking (PRME here: 0.240 against 0.255)."""
-    _check(model, SHARED_NEGATIVES, hit_slack=0.01, auc_slack=0.0015)
+def test_shared_negatives_stay_close_to_the_reference(model):
+    """An option, not the default, and NOT claimed to meet criterion (c): it costs 0.002-0.003 of test AUC while training is
+    young (FPMC's two seeds have come out 0.00503 below the reference's three, best iterations 34 / 38 against 40 / 40 / 40)
+    and up to 0.015 of HIT@50 at the top of the ranking (PRME here: 0.240 against 0.255).  What is held: AUC within 0.0065 at
+    the best checkpoint, HIT@50 within the bound plus 0.01."""
+    _check(model, SHARED_NEGATIVES, hit_slack=0.01, auc_slack=0.0015, above=0.01)
 
 
 @pytest.mark.parametrize("model", HISTORY)
-def test_history_pairs_follow_the_reference(model):
-    _check(model, HISTORY_PAIRS, above=0.015)
-
-
-@pytest.mark.parametrize("model", ["Fossil", "REBUS"])
-def test_history_models_with_atomics_on_every_row_follow_the_reference(model):
-    """Fossil's trajectory means are allowed 0.008 (AUC) / 0.009 (HIT@50) below - measured 0.0037 .. 0.0063 and 0.0033 .. 0.0068
-    from run to run: it overfits a little faster after its peak; its best checkpoint is held to the common bounds."""
-    fossil = model == "Fossil"
-    _check(model, [("update_policy", 0), ("user_batch", 1)], traj_auc_slack=0.003 if fossil else 0.0, hit_slack=0.003 if fossil else 0.0, above=0.015)
+def test_history_models_follow_the_reference(model):
+    """What rec_create selects at this size (575k steps per epoch): float atomics on every row, one tuple per history walk.
+    Two-sided bounds at the best checkpoint.  Fossil / FossilSimple's trajectory means are allowed 0.003 more below (AUC
+    0.0037 .. 0.0063 and HIT@50 0.0033 .. 0.0068 below from run to run): after their peak at epoch 3-4 every parallel run
+    overfits a little faster than the sequential one - sums of steps computed from the same stale row."""
+    fossil = model != "REBUS"
+    _check(model, [], traj_auc_slack=0.003 if fossil else 0.0, hit_slack=0.003 if fossil else 0.0, seeds=(0, 1, 2))
 
 
 @pytest.mark.parametrize("model,world", [("BPRMF", 2), ("BPRMF", 4), ("FPMC", 4), ("TransRec", 2)])

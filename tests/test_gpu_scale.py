@@ -299,30 +299,38 @@ def test_full_shape_partition_is_a_permutation_grouped_by_slice(big, slices):
     assert hashed(T) == hashed(out)
 
 
-def test_full_shape_default_update_trains_like_atomics_on_every_row(corpus):
-    """Two epochs of the default update (hybrid scatter, one launch per epoch) against two epochs with float atomics on
-    every row and bias, the closest a parallel launch comes to the reference's sequential sums: test AUC within 0.002 and
-    HIT@50 within 0.02 of each other, both well above the untrained model, no parameter beyond 4 in magnitude.  (The guard
-    for update modes that look right on toy-size corpora and fall apart at this size: applied in one launch per epoch, the
-    owner mode reaches AUC 0.65 / HIT@50 0.0005 here.)"""
+@pytest.mark.parametrize("model", ["BPRMF", "FPMC", "TransRec"])
+def test_full_shape_default_update_trains_like_atomics_on_every_row(corpus, model):
+    """Two epochs of the default update (hybrid scatter) against two epochs with float atomics on every row and bias, the
+    closest a parallel launch comes to the reference's sequential sums, at the shape where the hybrid scatter switches on
+    by itself; means over four seeds (initialisation and sampler) each.  Test AUC within 0.002 of each other (single runs:
+    BPRMF 0.0002, FPMC 0.0001, TransRec 0.0017 apart), HIT@50 within 0.01 (after two epochs a single evaluation of HIT@50
+    moves by 0.004 .. 0.0095 from one seed to the next with all-atomics alone, so single runs cannot be held to less; the
+    means of four are), both well above the untrained model, no parameter beyond 4 in magnitude.  (The guard for update
+    modes that look right on toy-size corpora and fall apart at this size: applied in one launch per epoch, the owner mode
+    reaches AUC 0.65 / HIT@50 0.0005 here.)"""
     import torch
     import recommendation_amd as ra
     from recommendation_amd.capi import F32
     from recommendation_amd.sharded import item_table_tensors
     seq_off, seq_item, test, val = corpus
-    got = {}
-    for name, opts in (("default", []), ("atomics", [("update_policy", 0)])):
-        e = ra.Engine("BPRMF", I, seq_off, seq_item, test, val, K=K, lam=0.01, bias_reg=0.01, precision=F32)
-        for k, v in opts:
-            e.set_option(k, v)
-        e.init_params(seed=2024)
-        for ep in range(2):
-            e.sgd_epoch(0.05, e.steps_per_epoch, seed=99, epoch=ep)
-        e.sync()
-        s = e.eval_sums(50)
-        got[name] = (s[1] / s[7], s[3] / s[7], max(float(t.abs().max()) for t in item_table_tensors(e, torch.device("cuda:0"))))
-        e.close()
-    assert got["atomics"][0] > 0.72 and got["atomics"][1] > 0.06, got
-    assert abs(got["default"][0] - got["atomics"][0]) < 0.002, got
-    assert abs(got["default"][1] - got["atomics"][1]) < 0.02, got
-    assert got["default"][2] < 4.0 and got["atomics"][2] < 4.0, got
+    e = ra.Engine(model, I, seq_off, seq_item, test, val, K=K, L=3, lam=0.01, bias_reg=0.01, relation_reg=0.01, alpha=0.5, precision=F32)
+    got = {"default": [], "atomics": []}
+    for name, policy in (("default", 1), ("atomics", 0)):
+        e.set_option("update_policy", policy)       # 1 is what rec_create selects at this size
+        for seed in (99, 7, 31, 64):
+            e.init_params(seed=2024 + seed)
+            for ep in range(2):
+                e.sgd_epoch(0.05, e.steps_per_epoch, seed=seed, epoch=ep)
+            e.sync()
+            s = e.eval_sums(50)
+            got[name].append((s[1] / s[7], s[3] / s[7], max(float(t.abs().max()) for t in item_table_tensors(e, torch.device("cuda:0")))))
+    e.close()
+    d, a = np.array(got["default"]), np.array(got["atomics"])
+    msg = (model, "default", d.round(5).tolist(), "atomics", a.round(5).tolist())
+    print(msg)
+    floor_auc, floor_hit = {"BPRMF": (0.72, 0.06), "FPMC": (0.70, 0.05), "TransRec": (0.70, 0.05)}[model]
+    assert a[:, 0].min() > floor_auc and a[:, 1].min() > floor_hit, msg
+    assert abs(d[:, 0].mean() - a[:, 0].mean()) < 0.002, msg
+    assert abs(d[:, 1].mean() - a[:, 1].mean()) < 0.01, msg
+    assert d[:, 2].max() < 4.0 and a[:, 2].max() < 4.0, msg
