@@ -281,7 +281,8 @@ int rec_project_rows(rec_engine* e);
  *                   halves under power-of-two scales (three MFMAs per 32 contraction indices); 2: the FP32 matrix pipe; 0: the
  *                   fp64 sweep.  Tables or queries that are not finite always take the fp64 sweep.  (process-wide)
  *   "eval_screen_cap"  columns per query the screen may leave to fp64 (default 0 = n_items / 128 within 256 .. 4096, f32 screen:
- *                   max(64, n_items / 2048)); a query that needs more makes the whole sweep run again in fp64
+ *                   max(64, n_items / 2048)); queries that need more are swept again in fp64 - on their own when they are
+ *                   few (at most 1/8 of the queries), else the whole sweep moves to the next narrower margin
  *   "project_after_launch"  TransRec: 1 (default) = every update launch ends with the projection of all item rows onto the unit
  *                   ball; 0 = the caller does it (rec_project_rows), see there
  *   "eval_ranges"   ranges the screen cuts the catalog into, each swept by its own blocks (0, the default: one range
@@ -294,9 +295,11 @@ int rec_set_option(rec_engine* e, const char* name, int64_t value);
 
 /* HIP-event statistics gathered while "profile" = 1: which = 0 SGD update (in owner mode: the partition and the update
  * kernel together), 1 eval scoring kernel, 2 sampler, 3 the owner mode's partition alone.  Resets the counters.
- * which = 4 (not reset): how the last full-catalog sweep ran - *launches = 0 fp64, 1 the selected screen held, 2 a query
- * overflowed its list of undecided columns and fp64 took over, 3 the f16 screen overflowed and the f32 screen, tried next,
- * held; *total_ms = the number of columns the screen left to fp64, over all queries.
+ * which = 4 (not reset): how the last full-catalog sweep ran - *launches = 0 fp64, 1 the selected screen held, 2 fp64 took
+ * over (many queries overflowed their lists of undecided columns, or the operands are not finite / out of range), 3 the f16
+ * screen overflowed and the f32 screen, tried next, held, 4 a screen held except for a few queries (at most 1/8 of them) that
+ * overflowed their lists and were swept again on their own in fp64; *total_ms = the number of columns the screen left to
+ * fp64, over all queries.
  * which = 5 (not reset): the last rec_eval_topk - *launches = (user, context) lists produced by the fused sweep,
  * *total_ms = device time of that part (HIP events around its kernels). */
 int rec_kernel_stats(rec_engine* e, int which, double* total_ms, int64_t* launches);

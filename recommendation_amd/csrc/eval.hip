@@ -15,6 +15,8 @@
 #include "common.h"
 #include <math.h>
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -742,7 +744,7 @@ __device__ __forceinline__ void split16(float x, half_t& h, half_t& l)
 __global__ void __launch_bounds__(256) screen16_items_kernel(EvalDev ev, const float* __restrict__ seg0, const float* __restrict__ seg1, int I, int I_pad,
                                                              int KQ16, const unsigned* __restrict__ bounds, half_t* __restrict__ Th, half_t* __restrict__ Tl,
                                                              float* __restrict__ bs, int32_t* __restrict__ overflow, float past_end = INFINITY,
-                                                             const int32_t* __restrict__ order = nullptr)
+                                                             const int32_t* __restrict__ order = nullptr, bool own_margin = false)
 {
     const double sT = screen16_scale(bounds[2]), sq = screen16_scale(bounds[3]);
     const float sTf = (float)sT;
@@ -754,13 +756,24 @@ __global__ void __launch_bounds__(256) screen16_items_kernel(EvalDev ev, const f
         if (c < I) { if (k < ev.K1) x = seg0[j * ev.K1 + k]; else if (k < ev.K1 + ev.K2) x = seg1[j * ev.K2 + (k - ev.K1)]; }
         half_t h, l; split16(x * sTf, h, l);   // a power of two: the product is exact
         Th[i] = h; Tl[i] = l;
-        if (k == 0) bs[c] = c < I ? (float)(ev.bconst[j] * (sq * sT)) : past_end;
+        if (k == 0) {
+            float b = c < I ? (float)(ev.bconst[j] * (sq * sT)) : past_end;
+            if (own_margin && c < I) {
+                // The constant's own share of a column's error - its rounding to f32 and the rounding of the sum it enters,
+                // 3 u |b| at most - is not part of the queries' margins (which would have to carry max |b_j| over the whole
+                // catalog: a handful of items with large biases then made every column of every query undecided).  It is
+                // added to the constant itself, e = 6 u |b|: a column counts when score + e is below threshold - margin,
+                // and is decided when it lies further than margin + 2 e above (the sweep widens its window by 2.03 e per column).
+                b = b + 3.6e-7f * fabsf(b);
+            }
+            bs[c] = b;
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // the scaled constants must stay far from the end of f32's range
         const double bmax = (double)__uint_as_float(bounds[1]);
         const float tm = __uint_as_float(bounds[0]), em = __uint_as_float(bounds[2]), qm = __uint_as_float(bounds[3]);
-        if (!(bmax * (sq * sT) <= 1e30) || !(tm < INFINITY) || !(em < INFINITY) || !(qm < INFINITY)) *overflow = 1;
+        if (!(bmax * (sq * sT) <= 1e30) || !(tm < INFINITY) || !(em < INFINITY) || !(qm < INFINITY)) overflow[own_margin ? 1 : 0] = 1;
     }
 }
 
@@ -789,14 +802,15 @@ __global__ void __launch_bounds__(256) screen16_queries_kernel(EvalDev ev, int K
         const double rep = 3.3 * 4.0 * u * s * tmax;                                              // 3.3 * 2^-22: halves dropped or rounded away
         const double sub = 6.103515625e-05 * sqrt((double)KQ16) * (tmax / sq + s / sT);          // 2^-14 per element: holds even if the matrix pipe flushed f16 subnormals (rounding alone: 2^-25)
         const double acc = 2.0 * (KQ16 + 3) * u * 1.002 * s * tmax + KQ16 * (u / 64.0) * s * tmax;  // main products; cross products ((3 KQ + 3) 2 u 2^-10 <= KQ u / 64)
-        const double rnd = 4.0 * u * (bmax + ta + s * tmax);                                      // thresholds and constants rounded to f32, the two final additions, the subtraction
+        (void)bmax;                                                                               // the constants carry their own margin (screen16_items_kernel)
+        const double rnd = 4.0 * u * (ta + s * tmax);                                             // thresholds rounded to f32, the two final additions, the subtraction
         const double mq = 1.05 * (rep + sub + acc + rnd) + 1e-30;
         ev.qmar[w] = w < ev.nq ? __double2float_ru(mq * S * 1.000001) : 0.f;                       // a padding row decides nothing and lists nothing
         thr_s[w] = (float)(t1 * S);
         thr2_s[w] = (float)(t2 * S);
         // out of f32's comfortable range, or not finite (only a padding row's -inf threshold is): the fp64 sweep takes over
         const bool odd1 = !(isfinite(t1) ? fabs(t1 * S) <= 1e30 : (t1 < 0 && t1 == t1)), odd2 = !(isfinite(t2) ? fabs(t2 * S) <= 1e30 : (t2 < 0 && t2 == t2));
-        if (odd1 || odd2 || (w < ev.nq && !(mq * S <= 1e30))) *overflow = 1;
+        if (odd1 || odd2 || (w < ev.nq && !(mq * S <= 1e30))) overflow[1] = 1;
     }
 }
 
@@ -815,6 +829,7 @@ __global__ void __launch_bounds__(256, (Screen16Shape<KQ, TWO>::WAVES)) score_sc
     half_t* const tile_l = tiles + NI * STR;
     __shared__ float tile_b[NI];
     __shared__ int q_amb[QB];
+    __shared__ __align__(16) float q_win[QB];          // every query's own window
     __shared__ int cnt_lds[(TWO ? 2 : 1) * QB * 16];   // counts so far per (threshold, query, column lane): registers are short
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, quad = lane >> 4;
@@ -834,27 +849,28 @@ __global__ void __launch_bounds__(256, (Screen16Shape<KQ, TWO>::WAVES)) score_sc
     // add: 2 u (|threshold| + margin) + u window.  (A compare and an add-with-carry per result were a chain through VCC with
     // idle cycles in between, as long as the MFMAs themselves; NaN has no defined sign, so tables or queries that are not
     // finite never get here: the launcher sends them to the fp64 sweep.)
-    float thm1[MT][4], thm2[MT][4], marw = 0.f, thw = 0.f;
+    // Margin and window are per QUERY (thresholds of one wavefront's queries can differ by orders of magnitude, and so do the
+    // roundings they bring: one query with a threshold of 0.1 among 63 with thresholds of 1e-6 would otherwise hand its window
+    // to all of them).  The hot loop tests the smallest y of a sub-step against the wavefront's WIDEST window (one scalar);
+    // the rare sub-step that passes looks up each query's own window (q_win, LDS) before it lists anything.
+    float thm1[MT][4], thm2[MT][4], winw = 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int64_t qi = qblock + qw + mt * 16 + 4 * quad + r;
-            const float t1 = thr_s[qi], t2 = TWO ? thr2_s[qi] : 0.f;
-            marw = fmaxf(marw, ev.qmar[qi]);
-            if (t1 > -INFINITY) thw = fmaxf(thw, fabsf(t1));
-            if (TWO && t2 > -INFINITY) thw = fmaxf(thw, fabsf(t2));
-            thm1[mt][r] = t1; thm2[mt][r] = t2;
+            const float t1 = thr_s[qi], t2 = TWO ? thr2_s[qi] : 0.f, mq = ev.qmar[qi];
+            float thq = 0.f;
+            if (t1 > -INFINITY) thq = fabsf(t1);
+            if (TWO && t2 > -INFINITY) thq = fmaxf(thq, fabsf(t2));
+            const float wq = (2.f * mq + 1.2e-7f * (thq + mq)) * 1.000001f;
+            if (col == 0) q_win[qw + mt * 16 + 4 * quad + r] = wq;
+            winw = fmaxf(winw, wq);
+            thm1[mt][r] = t1 - mq; thm2[mt][r] = TWO ? t2 - mq : 0.f;
         }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { marw = fmaxf(marw, __shfl_xor(marw, o, 64)); thw = fmaxf(thw, __shfl_xor(thw, o, 64)); }
-    const float mar_w = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(marw)));
-    const float th_w = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(thw)));
-    const unsigned window = __float_as_uint((2.f * mar_w + 1.2e-7f * (th_w + mar_w)) * 1.000001f);
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) { thm1[mt][r] -= mar_w; if (TWO) thm2[mt][r] -= mar_w; }
+    for (int o = 32; o > 0; o >>= 1) winw = fmaxf(winw, __shfl_xor(winw, o, 64));
+    const float window_q = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(winw)));   // + twice the column's own constant margin: per lane
 
     half8_t ah[MT][NCH], al[MT][NCH];
 #pragma unroll
@@ -926,6 +942,9 @@ __global__ void __launch_bounds__(256, (Screen16Shape<KQ, TWO>::WAVES)) score_sc
             }
             bj = tile_b[sub * 16 + col];
         };
+        // this lane's column: undecided when 0 <= y <= the queries' window + 2.03 e_j, e_j = 6 u |b_j| the constant's own margin
+        // (one v_fma per sub-step; a column past the end of the catalog has b = 3e38: y is huge, the window 2e32)
+        unsigned window; float ej;
         // (Writing the MFMAs of sub-step s + 1 next to the epilogue of sub-step s, so that the scheduler could interleave
         // them, was measured and changed nothing: 133.0 against 132.6 ms for 2M queries.)
         read_frags(0);
@@ -934,6 +953,8 @@ __global__ void __launch_bounds__(256, (Screen16Shape<KQ, TWO>::WAVES)) score_sc
             const int j = item0 + sub * 16 + col;
             unsigned mn = 0xffffffffu;
             float sc[MT][4];
+            ej = 7.3e-7f * __builtin_fabsf(bj);
+            window = __float_as_uint(window_q + ej);
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
                 // b_j is added after the chains: as their starting value it would make every one of their roundings relative
@@ -970,15 +991,18 @@ __global__ void __launch_bounds__(256, (Screen16Shape<KQ, TWO>::WAVES)) score_sc
             }
             if (++nbits == 32) { nbits = 0; add_up(~0u); }
             if (__ballot(mn <= window)) {
-            // some score of the wavefront lies within the margin of a threshold: which ones
+            // some score of the wavefront lies within the widest window of a threshold: which ones lie within their own query's
             unsigned open1 = 0, open2 = 0;   // bit (4 mt + r)
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++)
+            for (int mt = 0; mt < MT; mt++) {
+                const float4_t w4 = *reinterpret_cast<const float4_t*>(&q_win[qw + mt * 16 + 4 * quad]);
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    open1 |= (unsigned)(__float_as_uint(sc[mt][r] - thm1[mt][r]) <= window) << (4 * mt + r);
-                    if (TWO) open2 |= (unsigned)(__float_as_uint(sc[mt][r] - thm2[mt][r]) <= window) << (4 * mt + r);
+                    const unsigned wqe = __float_as_uint(w4[r] + ej);
+                    open1 |= (unsigned)(__float_as_uint(sc[mt][r] - thm1[mt][r]) <= wqe) << (4 * mt + r);
+                    if (TWO) open2 |= (unsigned)(__float_as_uint(sc[mt][r] - thm2[mt][r]) <= wqe) << (4 * mt + r);
                 }
+            }
             unsigned open = open1 | open2;
             while (open) {
                 const int e = __ffs(open) - 1;
@@ -1167,7 +1191,10 @@ __global__ void __launch_bounds__(256) correct_clicked_kernel(DevModel m, EvalDe
     // one list of (item, weight, thresholds it applies to): the clicked items (-multiplicity; the fp64 sweeps never count
     // the held-out pair, the screen counts it like any column), then the held-out pair where the screen counted it and
     // the click list does not take it out, then the columns the screen left open (+1 where the threshold is above the score)
-    const int na = ev.amb ? (ev.amb_cnt[w] < ev.amb_cap ? ev.amb_cnt[w] : ev.amb_cap) : 0;
+    // (a query marked -1 overflowed its list and was swept again on its own in fp64, the held-out pair excluded there)
+    const int acnt = ev.amb ? ev.amb_cnt[w] : 0;
+    const bool heldout_counted = ev.heldout_counted && acnt >= 0;
+    const int na = acnt < 0 ? 0 : acnt < ev.amb_cap ? acnt : ev.amb_cap;
     const int32_t* open = ev.amb ? ev.amb + (int64_t)w * ev.amb_cap : nullptr;
     const int total = nc + 2 + na;
     int dc = 0, dc2 = 0;
@@ -1177,12 +1204,12 @@ __global__ void __launch_bounds__(256) correct_clicked_kernel(DevModel m, EvalDe
         if (idx < nc) {
             e = clk[idx];
             wgt = -(ev.item_mult ? ev.item_mult[e] : 1);
-            if ((e == test || e == val) && !ev.heldout_counted) wgt = 0;
+            if ((e == test || e == val) && !heldout_counted) wgt = 0;
         } else if (idx < nc + 2) {
             const int h = idx - nc;
             e = h == 0 ? test : val;
             const bool done = h == 0 ? test_clicked : (val_clicked || val == test);
-            wgt = (ev.heldout_counted && e >= 0 && !done) ? -1 : 0;
+            wgt = (heldout_counted && e >= 0 && !done) ? -1 : 0;
         } else if (idx < total) {
             const int ent = open[idx - nc - 2];
             e = ent & 0x0fffffff; which = ent >> 28; wgt = 1;
@@ -1305,6 +1332,27 @@ __global__ void query_items_kernel(DevModel m, EvalDev ev, int32_t* qtest, int32
     int t = -1, v = -1;
     if (i < ev.nq) { const int u = m.eval_users[i / ev.nctx]; t = m.test_item[u]; v = m.val_item[u]; }
     qtest[i] = t; qval[i] = v;
+}
+
+// the queries listed in idx as a compact batch of their own (one wavefront per query), and their counts back
+__global__ void __launch_bounds__(256) gather_queries_kernel(EvalDev ev, EvalDev sub, const int32_t* __restrict__ idx, const int32_t* __restrict__ qtest,
+                                                             const int32_t* __restrict__ qval, int32_t* __restrict__ sub_test, int32_t* __restrict__ sub_val)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (w >= sub.nq) return;
+    const int64_t q = idx[w];
+    for (int k = lane; k < ev.KQ; k += 64) sub.Q[(int64_t)w * ev.KQ + k] = ev.Q[q * ev.KQ + k];
+    if (lane == 0) { sub.thr[w] = ev.thr[q]; sub.thr2[w] = ev.thr2[q]; sub_test[w] = qtest[q]; sub_val[w] = qval[q]; }
+}
+__global__ void scatter_counts_kernel(EvalDev ev, EvalDev sub, const int32_t* __restrict__ idx)
+{
+    const int w = (int)((int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+    if (w >= sub.nq) return;
+    const int64_t q = idx[w];
+    ev.cnt[q] = sub.cnt[w];
+    if (ev.nctx == 1) ev.cnt2[q] = sub.cnt2[w];
+    ev.amb_cnt[q] = -1;          // nothing left undecided for this query, and its held-out pair has not been counted
 }
 
 template <class T, bool TWO, bool STORE>
@@ -1518,9 +1566,9 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
         EV_TRY(alloc((void**)&ev.qmar, sizeof(float) * ev.nq_pad));
         EV_TRY(alloc((void**)&ev.amb, sizeof(int32_t) * (size_t)ev.nq_pad * ev.amb_cap));
         EV_TRY(alloc((void**)&ev.amb_cnt, sizeof(int32_t) * ev.nq_pad));
-        EV_TRY(alloc((void**)&ev.amb_overflow, sizeof(int32_t)));
+        EV_TRY(alloc((void**)&ev.amb_overflow, sizeof(int32_t) * 2));   // [0] a list overflowed, [1] operands the screen cannot take
         EV_TRY(alloc((void**)&bounds, sizeof(unsigned) * 2));
-        EV_TRY(hipMemsetAsync(ev.amb_overflow, 0, sizeof(int32_t), st));
+        EV_TRY(hipMemsetAsync(ev.amb_overflow, 0, sizeof(int32_t) * 2, st));
         EV_TRY(hipMemsetAsync(bounds, 0, sizeof(unsigned) * 2, st));
         // A block keeps its queries for a sweep of the catalog, so a launch has nq_pad / qblock blocks: with few queries (a
         // rank's share of the users, a small corpus) they do not fill the chip evenly - 977 blocks on 768 resident places run
@@ -1572,7 +1620,7 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
         EV_TRY(hipMemsetAsync(b4, 0, sizeof(unsigned) * 4, st));
         hipLaunchKernelGGL(screen16_bounds_kernel, dim3(1024), dim3(256), 0, st, ev, (const float*)seg0_cols, (const float*)seg1_cols, I, b4);
         hipLaunchKernelGGL(screen16_items_kernel, dim3(2048), dim3(256), 0, st, ev, (const float*)seg0_cols, (const float*)seg1_cols, I, I_pad, KQ16,
-                           (const unsigned*)b4, Th, Tl, bs, ev.amb_overflow);
+                           (const unsigned*)b4, Th, Tl, bs, ev.amb_overflow, 3.0e38f, (const int32_t*)nullptr, true);
         hipLaunchKernelGGL(screen16_queries_kernel, dim3(blocks_for_waves(ev.nq_pad)), dim3(256), 0, st, ev, KQ16, (const unsigned*)b4, Qh, Ql, thr_s, thr2_s,
                            ev.amb_overflow);
         ev.heldout_counted = 1;
@@ -1586,17 +1634,72 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
     }
     if (rc) { release(); return rc; }
     if (screen) {
-        // a query with more undecided columns than its list holds (tables with huge norms, a model that has diverged):
-        // the whole sweep is done again in fp64
-        int32_t over = 0;
-        EV_TRY(hipMemcpyAsync(&over, ev.amb_overflow, sizeof over, hipMemcpyDeviceToHost, st));
+        // A query with more undecided columns than its list holds (a user with a history of thousands of clicks, tables
+        // with huge norms, a model that has diverged).  A few such queries are swept again on their own in fp64; many send
+        // the whole sweep to the next narrower margin (f16 -> f32 screen -> fp64); operands the screen cannot take (not
+        // finite, out of range) send it to fp64 directly.
+        int32_t over2[2] = {0, 0};
+        EV_TRY(hipMemcpyAsync(over2, ev.amb_overflow, sizeof over2, hipMemcpyDeviceToHost, st));
         EV_TRY(hipStreamSynchronize(st));
-        bool second_try = false;
-        if (over && screen16) {
+        int32_t over = over2[0] | over2[1];
+        bool second_try = false, partial = false;
+        if (getenv("RECSYS_DEBUG_SCREEN")) {
+            std::vector<int32_t> ac(ev.nq);
+            (void)hipMemcpy(ac.data(), ev.amb_cnt, sizeof(int32_t) * ev.nq, hipMemcpyDeviceToHost);
+            int64_t tot = 0, nover = 0; int mx = 0, arg = 0;
+            for (int q = 0; q < ev.nq; q++) { tot += ac[q]; nover += ac[q] > ev.amb_cap; if (ac[q] > mx) { mx = ac[q]; arg = q; } }
+            fprintf(stderr, "[screen] flags %d %d, cap %d, undecided total %lld, queries over %lld of %d, max %d at query %d\n", over2[0], over2[1], ev.amb_cap,
+                    (long long)tot, (long long)nover, ev.nq, mx, arg);
+        }
+        auto redo_overflowing_in_fp64 = [&](bool* done) -> int {
+            *done = false;
+            std::vector<int32_t> ac(ev.nq);
+            EV_TRY(hipMemcpy(ac.data(), ev.amb_cnt, sizeof(int32_t) * ev.nq, hipMemcpyDeviceToHost));
+            std::vector<int32_t> idx;
+            for (int q = 0; q < ev.nq; q++) if (ac[q] > ev.amb_cap) idx.push_back(q);
+            if (idx.empty() || (int64_t)idx.size() * 8 > ev.nq) return 0;
+            const int qb64 = 4 * mt * 16;
+            EvalDev e2 = ev;
+            e2.nq = (int)idx.size(); e2.nq_pad = ((e2.nq + qb64 - 1) / qb64) * qb64;
+            e2.amb = nullptr; e2.ranges = 1;
+            int32_t *d_idx = nullptr, *sub_test = nullptr, *sub_val = nullptr;
+            EV_TRY(alloc((void**)&d_idx, sizeof(int32_t) * e2.nq));
+            EV_TRY(alloc((void**)&sub_test, sizeof(int32_t) * e2.nq_pad));
+            EV_TRY(alloc((void**)&sub_val, sizeof(int32_t) * e2.nq_pad));
+            EV_TRY(alloc((void**)&e2.Q, sizeof(double) * (size_t)e2.nq_pad * ev.KQ));
+            EV_TRY(alloc((void**)&e2.thr, sizeof(double) * e2.nq_pad));
+            EV_TRY(alloc((void**)&e2.thr2, sizeof(double) * e2.nq_pad));
+            EV_TRY(alloc((void**)&e2.cnt, sizeof(int32_t) * e2.nq_pad));
+            EV_TRY(alloc((void**)&e2.cnt2, sizeof(int32_t) * e2.nq_pad));
+            EV_TRY(hipMemcpyAsync(d_idx, idx.data(), sizeof(int32_t) * e2.nq, hipMemcpyHostToDevice, st));
+            EV_TRY(hipMemsetAsync(sub_test, 0xff, sizeof(int32_t) * e2.nq_pad, st));
+            EV_TRY(hipMemsetAsync(sub_val, 0xff, sizeof(int32_t) * e2.nq_pad, st));
+            EV_TRY(hipMemsetAsync(e2.Q, 0, sizeof(double) * (size_t)e2.nq_pad * ev.KQ, st));
+            hipLaunchKernelGGL(fill_f64_kernel, dim3(64), dim3(256), 0, st, e2.thr, (int64_t)e2.nq_pad, -INFINITY);
+            hipLaunchKernelGGL(fill_f64_kernel, dim3(64), dim3(256), 0, st, e2.thr2, (int64_t)e2.nq_pad, -INFINITY);
+            hipLaunchKernelGGL(gather_queries_kernel, dim3(blocks_for_waves(e2.nq)), dim3(256), 0, st, ev, e2, (const int32_t*)d_idx, (const int32_t*)qtest,
+                               (const int32_t*)qval, sub_test, sub_val);
+            // the fp64 sweep never counts the held-out pair (the positive's own column would be compared with a sum formed in
+            // another order than the threshold's): these queries are marked, and correct_clicked_kernel leaves the pair alone
+            int rc2 = ev.nctx == 1 ? launch_score<T, true, false>(e2, seg0_cols, seg1_cols, NC, sub_test, sub_val, st)
+                                   : launch_score<T, false, false>(e2, seg0_cols, seg1_cols, NC, sub_test, sub_val, st);
+            if (rc2) return rc2;
+            hipLaunchKernelGGL(scatter_counts_kernel, dim3((e2.nq + 255) / 256), dim3(256), 0, st, ev, e2, (const int32_t*)d_idx);
+            EV_TRY(hipGetLastError());
+            EV_TRY(hipStreamSynchronize(st));      // idx (host vector) has been copied
+            *done = true;
+            return 0;
+        };
+        if (over2[0] && !over2[1]) {
+            rc = redo_overflowing_in_fp64(&partial);
+            if (rc) { release(); return rc; }
+            if (partial) over = 0;
+        }
+        if (over && screen16 && !over2[1]) {
             // the f32 screen's margin is less than half as wide: it may hold where the f16 screen did not, at a quarter of
             // the fp64 sweep's time
             second_try = true;
-            EV_TRY(hipMemsetAsync(ev.amb_overflow, 0, sizeof(int32_t), st));
+            EV_TRY(hipMemsetAsync(ev.amb_overflow, 0, sizeof(int32_t) * 2, st));
             EV_TRY(hipMemsetAsync(bounds, 0, sizeof(unsigned) * 2, st));
             EV_TRY(hipMemsetAsync(ev.amb_cnt, 0, sizeof(int32_t) * ev.nq_pad, st));
             if (ev.ranges > 1) {
@@ -1605,14 +1708,20 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
             }
             rc = run_f32_screen();
             if (rc) { release(); return rc; }
-            EV_TRY(hipMemcpyAsync(&over, ev.amb_overflow, sizeof over, hipMemcpyDeviceToHost, st));
+            EV_TRY(hipMemcpyAsync(over2, ev.amb_overflow, sizeof over2, hipMemcpyDeviceToHost, st));
             EV_TRY(hipStreamSynchronize(st));
+            over = over2[0] | over2[1];
+            if (over2[0] && !over2[1]) {
+                rc = redo_overflowing_in_fp64(&partial);
+                if (rc) { release(); return rc; }
+                if (partial) over = 0;
+            }
         }
-        g_screen_mode = over ? 2 : second_try ? 3 : 1; g_screen_open = 0;
+        g_screen_mode = over ? 2 : partial ? 4 : second_try ? 3 : 1; g_screen_open = 0;
         if (profile) {
             std::vector<int32_t> open(ev.nq);
             EV_TRY(hipMemcpy(open.data(), ev.amb_cnt, sizeof(int32_t) * ev.nq, hipMemcpyDeviceToHost));
-            for (int32_t x : open) g_screen_open += x;
+            for (int32_t x : open) g_screen_open += x > 0 ? x : 0;
         }
         if (over) {
             ev.amb = nullptr; ev.heldout_counted = 0;
