@@ -177,3 +177,37 @@ def test_train_with_user_shards_in_one_process(workdir, name, extra):
     m = re.search(r"Test AUC = ([0-9.]+), Val AUC = ([0-9.]+)", single)
     for n in (2, 3):
         assert abs(aucs[n][0] - float(m.group(1))) < 0.012 and abs(aucs[n][1] - float(m.group(2))) < 0.012, (n, aucs[n], m.groups())
+
+
+@pytest.mark.gpu
+def test_first_benchmark_configuration_as_shipped(workdir):
+    """`./train 01-Data/ML1M-atmost-5.txt 0 0 1 1 10 0.01 0 0 -0.6 100 03-Models/my_model REBUS`, the command the reference
+    ships with (minCount 1, L 1, alpha -0.6, 100 iterations), end to end through the CLI on the engine; then criterion (b)
+    through the command line: the model file the REFERENCE binary saved for this very command (tests/golden/ml5_REBUS_mc1_L1:
+    its 6-decimal parameters and the metrics its own AUC() printed for them) is put where the CLI looks for it and scored
+    with 0 iterations - AUC and HIT@50 within 1e-6 of the reference's."""
+    args = (f"01-Data/{ML5}.txt", 0, 0, 1, 1, 10, 0.01, 0, 0, -0.6)
+    out = run(workdir, *args, 100, "03-Models/my_model", "REBUS")
+    assert "ss : 96-FSUB/ML1M-atmost-5_root_fsub_minCount_1_L_1.txt" in out
+    assert " --NW : 31339 -- " in out
+    assert len(re.findall(r"^Iter: \d+, took ", out, flags=re.M)) == 100
+    assert len(re.findall(r"^\[Valid AUC = ", out, flags=re.M)) == 1          # REBUS validates every 100 iterations (REBUS.cpp:578)
+    m = re.search(r"Test AUC = ([0-9.]+), Val AUC = ([0-9.]+)", out)
+    g, model, co, ci, labels = fixture_case("REBUS_mc1_L1", "ml5")
+    ref = g["metrics"]                                                          # AUC_val AUC_test HIT_val HIT_test MRR_val MRR_test var
+    # 100 iterations of the reference end at test AUC ref[1]; a parallel run of the same length lands near it
+    assert abs(float(m.group(1)) - ref[1]) < 0.02, (m.groups(), ref[:2])
+    saved = [f for f in os.listdir(workdir / "03-Models") if f.startswith("my_model__REBUS_K_10_minCount_1_L_1")]
+    assert len(saved) == 1, saved
+    assert len(parse_saved(workdir / "03-Models" / saved[0])) == 31339
+    # the reference's own saved parameters in its own text format (model.cpp:176-192), under the same name
+    W = g["W_micro"].astype(np.int64)
+    body = ", ".join(("-" if v < 0 else "") + "%d.%06d" % divmod(abs(int(v)), 1000000) for v in W)
+    with open(workdir / "03-Models" / saved[0], "w") as f:
+        f.write('{\n  "NW": %d,\n  "W": [%s]\n}\n' % (len(W), body))
+    out = run(workdir, *args, 0, "03-Models/my_model", "REBUS")
+    assert "loading parameters from 03-Models/" + saved[0] in out and "Iter: " not in out
+    m = re.search(r"Test AUC = ([0-9.]+), Val AUC = ([0-9.]+)", out)
+    h = re.search(r"Test HIT50 = ([0-9.]+), Val HIT50 = ([0-9.]+)", out)
+    assert abs(float(m.group(1)) - ref[1]) < 1e-6 and abs(float(m.group(2)) - ref[0]) < 1e-6, (m.groups(), ref)
+    assert abs(float(h.group(1)) - ref[3]) < 1e-6 and abs(float(h.group(2)) - ref[2]) < 1e-6, (h.groups(), ref)
