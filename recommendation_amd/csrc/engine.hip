@@ -1063,7 +1063,13 @@ extern "C" int rec_eval_topk(rec_engine* e, const int32_t* users, int32_t n_user
 // in one kernel when the shards share a device, else as delta_r = table_r - base, one RCCL all-reduce (sum) per table
 // over the shards' devices, table_r = base + sum.  RCCL is loaded when the first multi-device combine needs it.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
+// The few RCCL names the multi-device branch uses, declared here so that a build (and a single-GPU run) needs neither the
+// RCCL headers nor the library: the values are those of rccl.h (ncclSuccess 0, ncclSum 0, ncclFloat32 7, ncclFloat64 8).
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+typedef int ncclRedOp_t;
+enum { ncclSuccess = 0, ncclSum = 0, ncclFloat32 = 7, ncclFloat64 = 8 };
 namespace {
 struct ShardPtrs { void* tab[16]; };
 template <class T>
@@ -1084,6 +1090,7 @@ __global__ void shard_axpy_kernel(T* __restrict__ tab, const T* __restrict__ bas
 struct Rccl {
     void* lib = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
@@ -1101,16 +1108,22 @@ int rccl_comms(const std::vector<int>& devs, ncclComm_t** out)
         if (!r.lib) r.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
         if (!r.lib) { rec_set_error(std::string("shards on several devices need RCCL: ") + dlerror()); return -2; }
         r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.lib, "ncclCommInitAll");
+        r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
         r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
         r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
         r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
         r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
-        if (!r.CommInitAll || !r.AllReduce || !r.GroupStart || !r.GroupEnd || !r.GetErrorString) { rec_set_error("librccl lacks an expected symbol"); r.lib = nullptr; return -2; }
+        if (!r.CommInitAll || !r.CommDestroy || !r.AllReduce || !r.GroupStart || !r.GroupEnd || !r.GetErrorString) {
+            rec_set_error("librccl lacks an expected symbol"); (void)dlclose(r.lib); r.lib = nullptr; return -2;
+        }
     }
     if (r.devs != devs) {
+        // another device list than last time: the old communicators go first
+        for (ncclComm_t c : r.comms) if (c) (void)r.CommDestroy(c);
+        r.devs.clear();
         r.comms.assign(devs.size(), nullptr);
         const ncclResult_t rc = r.CommInitAll(r.comms.data(), (int)devs.size(), devs.data());
-        if (rc != ncclSuccess) { rec_set_error(std::string("ncclCommInitAll: ") + r.GetErrorString(rc)); r.devs.clear(); return -2; }
+        if (rc != ncclSuccess) { rec_set_error(std::string("ncclCommInitAll: ") + r.GetErrorString(rc)); r.comms.clear(); return -2; }
         r.devs = devs;
     }
     *out = r.comms.data();
@@ -1163,9 +1176,10 @@ extern "C" int rec_shards_begin_round(rec_engine* const* shards, int n)
                 ENG_HIP(hipMemcpyAsync(e->round_base[t], (char*)e->W + e->tables[t].dev_off * e->elem_size, (size_t)(e->tables[t].rows * e->tables[t].cols) * e->elem_size,
                                        hipMemcpyDeviceToDevice, e->st));
     }
-    if (one_device) {
-        // the other shards' streams must not start the round before the copy has been taken
-        ENG_HIP(hipStreamSynchronize(shards[0]->st));
+    // the base has been taken before any shard's stream starts the round (shards on one device share the first one's copy)
+    for (int r = 0; r < (one_device ? 1 : n); r++) {
+        ENG_HIP(hipSetDevice(shards[r]->desc.device));
+        ENG_HIP(hipStreamSynchronize(shards[r]->st));
     }
     return 0;
 }
