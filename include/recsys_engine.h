@@ -105,12 +105,15 @@ int rec_restore_best(rec_engine* e);
  *   TransRec* (u,x,y,yn)  Fossil (u,t,neg,-) and REBUS (u,t-1,neg,-) with target seq[u][t] */
 int rec_sgd_replay(rec_engine* e, double lr, const int32_t* tuples, int64_t n, int mode);
 
-/* No counterpart in the reference.  rec_sgd_replay for callers that cannot allocate device memory (code under HIP
- * graph capture, tight serving loops, harnesses that forbid hipMalloc): the same kernels, with the tuples staged in
- * a fixed 1 MiB device array that is part of the library's code object instead of a buffer grown on demand.  It calls
- * no hipMalloc / hipFree and creates no HIP events ("profile" does not time it).  n <= 65536 tuples per call; larger
- * n is rejected with an error.  Every engine on one GPU shares that GPU's array: calls (of any engines) that overlap
- * on one GPU race.  Results are those of rec_sgd_replay on the same tuples. */
+/* No counterpart in the reference.  rec_sgd_replay for callers that cannot allocate device memory (harnesses that forbid
+ * hipMalloc, tight serving loops that must not touch the allocator): the same kernels, with the tuples staged in a fixed
+ * 1 MiB device array that is part of the library's code object instead of a buffer grown on demand.  It calls no
+ * hipMalloc / hipFree and creates no HIP events ("profile" does not time it); like rec_sgd_replay it copies the tuples
+ * from the caller's host memory and waits for its kernels, so it is not meant to be captured into a HIP graph.
+ * n <= 65536 tuples per call; larger n, and an unknown mode, are rejected before anything is enqueued.  Every engine on
+ * one GPU shares that GPU's array: calls (of any engines) that overlap on one GPU race.  Results are those of
+ * rec_sgd_replay on the same tuples, except with "owner_neg" 1, whose partition pass needs the engine's own buffers and is
+ * not taken here (the plain Hogwild kernel applies the tuples instead). */
 int rec_sgd_replay_static(rec_engine* e, double lr, const int32_t* tuples, int64_t n, int mode);
 
 /* replaces: <Model>::oneiteration / oneIteration (e.g. BPRMF.cpp:107-150): n_steps tuples drawn on
@@ -280,7 +283,7 @@ int rec_project_rows(rec_engine* e);
  *                   fp64, so the counts are those of the fp64 sweep.  1 (default): the 16-bit pipe, every operand as two f16
  *                   halves under power-of-two scales (three MFMAs per 32 contraction indices); 2: the FP32 matrix pipe; 0: the
  *                   fp64 sweep.  Tables or queries that are not finite always take the fp64 sweep.  (process-wide)
- *   "eval_screen_cap"  columns per query the screen may leave to fp64 (default 0 = n_items / 128 within 256 .. 4096, f32 screen:
+ *   "eval_screen_cap"  columns per query the screen may leave to fp64 (default 0 = n_items / 512 within 128 .. 1024, f32 screen:
  *                   max(64, n_items / 2048)); queries that need more are swept again in fp64 - on their own when they are
  *                   few (at most 1/8 of the queries), else the whole sweep moves to the next narrower margin
  *   "project_after_launch"  TransRec: 1 (default) = every update launch ends with the projection of all item rows onto the unit

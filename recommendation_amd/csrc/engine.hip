@@ -759,6 +759,7 @@ static int check_tuples(const rec_engine* e, const int32_t* t, int64_t n)
 // around every launch when "profile" is on (creating events allocates)
 static int replay_tuples(rec_engine* e, double lr, const int32_t* tuples, int64_t n, int mode, int4* dev_buf, bool timed)
 {
+    if (mode != REC_REPLAY_SEQUENTIAL && mode != REC_REPLAY_HOGWILD) { rec_set_error("unknown replay mode"); return -1; }   // before anything is enqueued
     if (int rc = check_tuples(e, tuples, n)) return rc;
     if (e->desc.model == REC_FOSSIL || e->desc.model == REC_REBUS) {
         // target positions must lie inside the user's training sequence

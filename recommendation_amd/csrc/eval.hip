@@ -1549,22 +1549,20 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
     unsigned* bounds = nullptr;
     if (!l1 && n_subset <= 0) { g_screen_mode = 0; g_screen_open = 0; }
     if (screen) {
-        // undecided columns per query grow with the catalog (margin x columns per unit of score): room for I / 2048 of them,
-        // at least 64, unless the caller has fixed it
-        // The f16 screen's margin is the wider one, and the margin of a query grows with its norm: at the 1M x 200k shape a
-        // trained Fossil model leaves 17 columns per query on average and more than 224 for a few users with histories of
-        // thousands of clicks - which sent the WHOLE sweep to fp64 (1.08 s instead of 0.2).  The lists are virtual space
-        // until written, so they are sized generously: I / 128 columns (256 .. 4096), within 32 GB for all queries.
-        if (screen16) {
-            int64_t cap = std::min<int64_t>(4096, std::max<int64_t>(256, ((I / 128 + 31) / 32) * 32));
-            const int64_t room = ((int64_t)32 << 30) / ((int64_t)ev.nq_pad * 4);
-            if (cap > room) cap = std::max<int64_t>(64, room / 32 * 32);
-            ev.amb_cap = g_screen_cap > 0 ? g_screen_cap : (int)cap;
-        } else {
-            ev.amb_cap = g_screen_cap > 0 ? g_screen_cap : std::max(64, ((I / 2048 + 31) / 32) * 32);
-        }
+        // Undecided columns per query grow with the catalog (margin x columns per unit of score); a trained model leaves 10-25
+        // per query at 200k items, a few users with histories of thousands of clicks some hundreds.  The lists are real
+        // memory (nq x cap x 4 bytes: 3 GB for 2M queries at 384), so they are sized for the bulk - I / 512 columns within
+        // 128 .. 1024 for the f16 screen, max(64, I / 2048) for the f32 screen - and the few queries that need more are swept
+        // again on their own in fp64.  If the allocation fails the lists are halved (down to 32 columns) before the screen
+        // is given up for the fp64 sweep.
+        if (screen16) ev.amb_cap = g_screen_cap > 0 ? g_screen_cap : (int)std::min<int64_t>(1024, std::max<int64_t>(128, ((I / 512 + 31) / 32) * 32));
+        else ev.amb_cap = g_screen_cap > 0 ? g_screen_cap : std::max(64, ((I / 2048 + 31) / 32) * 32);
         EV_TRY(alloc((void**)&ev.qmar, sizeof(float) * ev.nq_pad));
-        EV_TRY(alloc((void**)&ev.amb, sizeof(int32_t) * (size_t)ev.nq_pad * ev.amb_cap));
+        while (alloc((void**)&ev.amb, sizeof(int32_t) * (size_t)ev.nq_pad * ev.amb_cap) != hipSuccess) {
+            (void)hipGetLastError();
+            if (ev.amb_cap <= 32) { rec_set_error("no device memory for the screen's lists of undecided columns"); release(); return -2; }
+            ev.amb_cap = std::max(32, ev.amb_cap / 2);
+        }
         EV_TRY(alloc((void**)&ev.amb_cnt, sizeof(int32_t) * ev.nq_pad));
         EV_TRY(alloc((void**)&ev.amb_overflow, sizeof(int32_t) * 2));   // [0] a list overflowed, [1] operands the screen cannot take
         EV_TRY(alloc((void**)&bounds, sizeof(unsigned) * 2));

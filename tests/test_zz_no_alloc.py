@@ -63,5 +63,27 @@ def test_static_replay_hogwild_and_limits():
                 e.sgd_replay_static(0.05, np.zeros((65537, 4), np.int32), SEQUENTIAL)
             with pytest.raises(RuntimeError, match="out of range"):
                 e.sgd_replay_static(0.05, np.array([[10 ** 6, 0, 1, 0]], np.int32), SEQUENTIAL)
+            with pytest.raises(RuntimeError, match="unknown replay mode"):
+                e.sgd_replay_static(0.05, keep[:3], 7)
         e.close()
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_static_replay_leaves_the_device_allocator_alone():
+    """Free device memory (hipMemGetInfo) is the same before and after calls of the allocation-free entry point, in both
+    modes and for growing inputs - where rec_sgd_replay on the same fresh engine has to grow its tuple buffer."""
+    import torch
+    g, model, co, ci, labels = fixture_case("FPMC", "toy")
+    e = make_engine(g, model, co, ci, labels, F32)
+    e.upload(g["W0"])
+    t = g["tuples"]
+    e.sgd_replay_static(0.05, t[:8], SEQUENTIAL)       # first launches load the kernels' code
+    e.sgd_replay_static(0.05, t[:8], HOGWILD)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for n in (16, 200, 2000):
+        e.sgd_replay_static(0.05, t[:n], SEQUENTIAL)
+        e.sgd_replay_static(0.05, t[:n], HOGWILD)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0
+    e.close()
