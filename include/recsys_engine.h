@@ -244,6 +244,10 @@ int rec_project_rows(rec_engine* e);
  *                   holds four consecutive components per lane (16-byte row accesses, four tuples per wave-instruction at
  *                   K = 64); 0 = always the one-dword-per-lane form (which also serves every other K, f64 and the shared
  *                   negatives / positives)
+ *   "fused_sampler" 1 (default) = where the wide kernel applies and every step's draws are independent ("share_negative" 1,
+ *                   "share_positive" 1, "group_by_item" 0, "overlap" 0, "owner_neg" 0), rec_sgd_epoch launches no sampler: the
+ *                   update kernel draws tuple i of the epoch itself - the tuple rec_sample_tuples reports for step i of
+ *                   (seed, epoch) - and no tuple is written to or read from memory; 0 = sampler launch + update launch
  *   "update_policy" 0 = float atomics on every row, 1 = hybrid (plain stores for user rows, biases and the few
  *                   items drawn most often, atomics on the other item rows), 2 = plain racy stores
  *   "atomic"        the same as a bit mask: bit r = row r of the tuple, bit 8 = biases

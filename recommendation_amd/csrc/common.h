@@ -97,6 +97,9 @@ int launch_sgd_owner(const DevModel& m, int precision, const int4* partitioned, 
 bool sgd_wide_supported(const DevModel& m, int precision);
 int sgd_wide_owner_slices(const DevModel& m);
 int launch_sgd_wide(const DevModel& m, const int4* tuples, const int64_t* qoff, int slices, int64_t n, double lr, int atomic, int flush_at, hipStream_t st);
+// the same kernel drawing its own tuples: tuple i of the launch is step first_step + i of (seed, epoch), what launch_sampler
+// would have written to tuples[i] (independent draws: no shared users, negatives or positives)
+int launch_sgd_wide_sampled(const DevModel& m, int64_t n, int64_t first_step, uint64_t seed, uint64_t epoch, double lr, int atomic, hipStream_t st);
 // Stable-by-block partition of n tuples by (component `field`) / slice_rows into `slices` ranges of dst; qoff[slices+1]
 // (device) receives the range starts; slices = 256, 512 or 1024.  scratch: partition_scratch_bytes(n, slices).
 size_t partition_scratch_bytes(int64_t n, int slices);

@@ -56,6 +56,7 @@ struct rec_engine {
     int neg_share = 1;   // consecutive steps of an epoch that share their stream of negative candidates (group models)
     int user_batch = 1;  // consecutive steps of an epoch that share their user draw (history models)
     int wide = 1;        // 1: the wide form of the Hogwild kernel (sgd_wide.hip) where it applies
+    int fused_sampler = 1;   // 1: that kernel draws its own tuples where every step's draws are independent (no sampler launch, no tuple buffer)
     int owner = 0;       // 1: launches of >= owner_min tuples are partitioned by the negative's slice of the catalog and applied in owner mode
     int owner_flush = 8; // additions after which an LDS accumulator row is moved to memory
     int64_t owner_per_item = 8;   // owner mode: a launch holds at most this many tuples per item of the catalog
@@ -662,7 +663,12 @@ static int ensure_partition_scratch(rec_engine* e, int64_t n, int slices)
 // gradient in afterwards, so their launches are kept short (`global_window` tuples).
 static bool history_model(int model) { return model == REC_FOSSIL || model == REC_FOSSIL_SIMPLE || model == REC_REBUS; }
 
-static int launch_update(rec_engine* e, const int4* tuples, int64_t n, double lr, bool grouped = false, int user_batch = 1)
+// sampled (tuples == nullptr): the update kernel draws tuple i of this call itself, as step sampled->first_step + i of
+// (seed, epoch); only where can_fuse_sampler() holds
+struct SampledSource { int64_t first_step; uint64_t seed, epoch; };
+static bool can_fuse_sampler(const rec_engine* e);
+
+static int launch_update(rec_engine* e, const int4* tuples, int64_t n, double lr, bool grouped = false, int user_batch = 1, const SampledSource* sampled = nullptr)
 {
     const int model = e->desc.model;
     const bool history = model == REC_FOSSIL || model == REC_FOSSIL_SIMPLE || model == REC_REBUS;
@@ -686,7 +692,14 @@ static int launch_update(rec_engine* e, const int4* tuples, int64_t n, double lr
         const int64_t len = std::min(window, n - o);
         // owner mode: needs room for the partitioned copy, which is the second half of the engine's tuple buffer
         const bool use_wide = e->wide && !history && e->neg_share == 1 && e->pos_share == 1 && sgd_wide_supported(e->dm, e->desc.precision);
-        const bool in_own_buffer = e->tuples && tuples + o >= e->tuples && tuples + o + len <= e->tuples + e->tuples_cap;
+        const bool in_own_buffer = !sampled && e->tuples && tuples + o >= e->tuples && tuples + o + len <= e->tuples + e->tuples_cap;
+        if (sampled) {
+            if (int rc = launch_sgd_wide_sampled(e->dm, len, sampled->first_step + o, sampled->seed, sampled->epoch, lr, e->atomic, e->st)) return rc;
+            if (global_row) {
+                if (int rc = launch_apply_global(e->dm, e->desc.precision, lr, len, (double)e->global_cap, e->st, e->project_after_launch != 0)) return rc;
+            }
+            continue;
+        }
         if (owner_on && in_own_buffer && len >= e->owner_min) {
             const int slices = !use_wide ? sgd_owner_slices() : e->owner_slices ? e->owner_slices : sgd_wide_owner_slices(e->dm);
             const int slice_rows = (e->dm.I + slices - 1) / slices;
@@ -716,6 +729,14 @@ static int launch_update(rec_engine* e, const int4* tuples, int64_t n, double lr
         }
     }
     return 0;
+}
+
+// The default update of the group models (wide kernel, every step its own draws, one stream) needs no tuple buffer: the
+// kernel draws what the sampler would have written ("fused_sampler" 1, the default).
+static bool can_fuse_sampler(const rec_engine* e)
+{
+    return e->fused_sampler && !history_model(e->desc.model) && e->wide && e->neg_share == 1 && e->pos_share == 1 && e->group == 0 && !e->overlap &&
+           !e->owner && sgd_wide_supported(e->dm, e->desc.precision);
 }
 
 // ---- HIP-event bookkeeping: events are recorded around a launch and read back lazily
@@ -836,6 +857,20 @@ extern "C" int rec_sgd_epoch(rec_engine* e, double lr, int64_t n_steps, uint64_t
     const bool paired = !grouped && e->pos_share == 2 && sgd_runs_supported(e->desc.model);
     if (grouped || paired) { if (int rc = ensure_events(e)) return rc; }
     const int64_t cap = grouped ? chunk + 8 * (int64_t)std::sqrt((double)chunk) + 1024 : chunk;
+    const bool fused = can_fuse_sampler(e);
+    if (fused) {
+        if (e->dm.n_elig <= 0) { rec_set_error("no user (or source item) is eligible for sampling"); return -1; }
+        for (int64_t o = 0; o < n_steps; o += chunk) {
+            const int64_t len = std::min(chunk, n_steps - o);
+            const SampledSource src = {o, seed, epoch};
+            hipEvent_t a = nullptr, b = nullptr;
+            if (int rc = ev_begin(e, 0, &a, &b)) return rc;
+            if (int rc = launch_update(e, nullptr, len, lr, false, 1, &src)) return rc;
+            if (int rc = ev_end(e, 0, a, b)) return rc;
+            e->tuples_drawn += len;
+        }
+        return 0;
+    }
     if (e->tuples_cap < cap) { if (int rc = ensure_tuples(e, cap)) return rc; }
     hipEvent_t a = nullptr, b = nullptr;
     // By default the sampler of a chunk runs on the update stream, ahead of its update: sampling chunk c+1 next to
@@ -1310,6 +1345,7 @@ extern "C" int rec_set_option(rec_engine* e, const char* name, int64_t value)
     else if (s == "project_after_launch") e->project_after_launch = value != 0;
     else if (s == "pair_min_history") { if (value < 0 || value > (1 << 20)) { rec_set_error("pair_min_history must be in 0..2^20"); return -1; } e->dm.pair_min_hist = (int)value; }
     else if (s == "user_batch") { if (value != 1 && value != 2 && value != 4 && value != 8) { rec_set_error("user_batch must be 1, 2, 4 or 8"); return -1; } e->user_batch = (int)value; }
+    else if (s == "fused_sampler") { if (value != 0 && value != 1) { rec_set_error("fused_sampler must be 0 or 1"); return -1; } e->fused_sampler = (int)value; }
     else if (s == "wide") { if (value != 0 && value != 1) { rec_set_error("wide must be 0 or 1"); return -1; } e->wide = (int)value; }
     else if (s == "owner_neg") { if (value != 0 && value != 1) { rec_set_error("owner_neg must be 0 or 1"); return -1; } e->owner = (int)value; }
     else if (s == "owner_flush") { if (value < 1 || value > 65536) { rec_set_error("owner_flush must be in 1..65536"); return -1; } e->owner_flush = (int)value; }

@@ -296,7 +296,10 @@ __global__ void __launch_bounds__(OWNER ? OWNER_THREADS : 256) sgd_hogwild_kerne
                     if (p && (fold_reach == 2 || ((g >> 1) & 1) == 1) && g - 2 * d >= 0 && prev_idx == mine_idx) folded_bias = true;
                 }
             }
-            if (p && !folded_bias) scatter(p, delta, bs, ((atomic >> 8) & 1) && !bias_hot);
+            // owner mode: the tuples of a slice run side by side in one workgroup and name the same few negatives - as plain
+            // stores ("value loaded a batch ago + step") their bias steps would overwrite each other, so there the biases
+            // are always float atomics (the wide kernel sums them in LDS next to their rows)
+            if (p && !folded_bias) scatter(p, delta, bs, OWNER || (((atomic >> 8) & 1) && !bias_hot));
         }
         bs = bn; bias_hot = bias_hot_n; hf = hfn;
         b_p = b_n; b_n = b_nn;

@@ -25,7 +25,12 @@
 // by construction ("share_negative", "share_positive") are not folded here and stay with that kernel.
 #include "common.h"
 #include "sgd_step.h"
+#include "sampler_dev.h"
 #include <algorithm>
+
+// SAMPLE: the kernel draws its own tuples - step first_step + i of (seed, epoch), the tuple sampler_kernel would have written
+// to tuples[i] - instead of reading them: no sampler launch in front of it and no 16 bytes written and read back per tuple
+struct SampleArgs { uint64_t seed, epoch; int64_t first_step; };
 
 constexpr int WIDE_EPL = 4;
 constexpr int WIDE_OWNER_THREADS = 1024;   // one workgroup per CU in owner mode
@@ -47,10 +52,11 @@ __device__ __forceinline__ float fix_take(int* p) { return (float)atomicExch(p, 
 __device__ __forceinline__ float4 fix_take4(int* p) { return make_float4(fix_take(p), fix_take(p + 1), fix_take(p + 2), fix_take(p + 3)); }
 
 // FULL: K (and KK) == 4 * LPT, every lane of a group holds four live components (no width tests)
-template <int MODEL, int LPT, int B, bool OWNER, bool FULL>
+template <int MODEL, int LPT, int B, bool OWNER, bool FULL, bool SAMPLE = false>
 __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_kernel(DevModel m, const int4* __restrict__ tuples, int64_t n,
-                                                                                   float lr, int atomic, OwnerArgs ow)
+                                                                                   float lr, int atomic, OwnerArgs ow, SampleArgs sa)
 {
+    static_assert(!(SAMPLE && OWNER), "the owner mode applies tuples that a partition pass has ordered");
     using T = float;
     constexpr int R = Spec<MODEL>::R, NB = Spec<MODEL>::NB, EPL = WIDE_EPL;
     constexpr bool TR = MODEL == REC_TRANSREC || MODEL == REC_TRANSREC_L1;
@@ -173,19 +179,48 @@ __global__ void __launch_bounds__(OWNER ? WIDE_OWNER_THREADS : 256) sgd_wide_ker
         }
     };
 
+    // SAMPLE: a group draws the tuples of its next LPT / B batches in one go, one tuple per lane (every lane of the wavefront
+    // busy with a tuple of its own, as in sampler_kernel), and hands them out batch by batch.  The two dependent loads of
+    // a draw (the owner's record, then the item at the drawn position) are waited for once per LPT / B batches.
+    constexpr int QN = LPT / B;
+    int4 qt = make_int4(-1, 0, 0, 0); int64_t qb = 0; int qpos = QN;
+    auto fetch = [&](int64_t& bidx, int4 (&t)[B]) {
+        if constexpr (!SAMPLE) {
+            bidx = next_batch();
+            load_idx(bidx, t);
+        } else {
+            if (qpos == QN) {
+                int64_t mine = 0;
+#pragma unroll
+                for (int j = 0; j < QN; j++) { const int64_t bj = next_batch(); if (g / B == j) mine = bj; }
+                const int64_t i = mine * B + (g % B);
+                qb = mine;
+                qt = (mine < nbatch && i < n) ? sample_tuple<MODEL>(m, (uint64_t)(sa.first_step + i), sa.seed, sa.epoch, 1, 1) : make_int4(-1, 0, 0, 0);
+                qpos = 0;
+            }
+            bidx = __shfl(qb, qpos * B, LPT);
+#pragma unroll
+            for (int b = 0; b < B; b++) {
+                const int src = qpos * B + b;
+                t[b] = make_int4(__shfl(qt.x, src, LPT), __shfl(qt.y, src, LPT), __shfl(qt.z, src, LPT), __shfl(qt.w, src, LPT));
+            }
+            qpos++;
+        }
+    };
+
     int4 tp[B], tn[B];
     float4 v[B][R]; T bs;
     int hf; uint8_t bias_hot;
-    int64_t b_p = next_batch(), b_n = next_batch();
-    load_idx(b_p, tp);
-    load_idx(b_n, tn);
+    int64_t b_p, b_n;
+    fetch(b_p, tp);
+    fetch(b_n, tn);
     load_rows(tp, v, bs, hf, bias_hot);
     // The loop is left by the wavefront as a whole (the staged scatter reads across its lane groups): a group whose
     // claims have run past the end keeps going on invalid tuples, which load and write nothing.
     while (__ballot(b_p < nbatch)) {
         int4 tnn[B];
-        const int64_t b_nn = next_batch();
-        load_idx(b_nn, tnn);
+        int64_t b_nn;
+        fetch(b_nn, tnn);
         float4 vn[B][R]; T bn;
         int hfn; uint8_t bias_hot_n;
         load_rows(tn, vn, bn, hfn, bias_hot_n);
@@ -368,16 +403,18 @@ int sgd_wide_owner_slices(const DevModel& m)
 }
 
 template <int MODEL>
-static int wide_dispatch(const DevModel& m, const int4* tuples, int64_t n, double lr, int atomic, const int64_t* qoff, int slices, int flush_at, hipStream_t st)
+static int wide_dispatch(const DevModel& m, const int4* tuples, int64_t n, double lr, int atomic, const int64_t* qoff, int slices, int flush_at, hipStream_t st,
+                         const SampleArgs* sample = nullptr)
 {
     const int Kmax = m.K > m.KK ? m.K : m.KK;
     OwnerArgs ow = {nullptr, 0, 0, 0, 1, 64};
-    auto go = [&](auto kern, auto kern_owner, int lpt, int b) -> int {
+    const SampleArgs sa = sample ? *sample : SampleArgs{0, 0, 0};
+    auto go = [&](auto kern, auto kern_owner, auto kern_sample, int lpt, int b) -> int {
         if (qoff) {
             const size_t lds = wide_owner_layout(m, slices, ow);
             ow.qoff = qoff; ow.flush_at = flush_at < 1 ? 1 : flush_at;
             HIP_TRY(hipFuncSetAttribute((const void*)kern_owner, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern_owner, dim3(slices), dim3(WIDE_OWNER_THREADS), lds, st, m, tuples, n, (float)lr, atomic, ow);
+            hipLaunchKernelGGL(kern_owner, dim3(slices), dim3(WIDE_OWNER_THREADS), lds, st, m, tuples, n, (float)lr, atomic, ow, sa);
             return 0;
         }
         const int64_t groups_per_block = 256 / lpt;
@@ -389,15 +426,18 @@ static int wide_dispatch(const DevModel& m, const int4* tuples, int64_t n, doubl
         // claims of 64 batches where every group gets at least four of them, a split by stride below that
         ow.claim = nbatch_h >= 4 * 64 * blocks * groups_per_block ? 64 : 0;
         HIP_TRY(hipMemsetAsync(m.work_counter, 0, sizeof(int), st));   // the batch counter the groups claim from
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 4 * 1024, st, m, tuples, n, (float)lr, atomic, ow);
+        if (sample) hipLaunchKernelGGL(kern_sample, dim3((unsigned)blocks), dim3(256), 4 * 1024, st, m, tuples, n, (float)lr, atomic, ow, sa);
+        else hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 4 * 1024, st, m, tuples, n, (float)lr, atomic, ow, sa);
         return 0;
     };
     constexpr int R = Spec<MODEL>::R;
     int rc = 0;
     const bool full_k = m.K == m.KK || !(MODEL == REC_FPMC || MODEL == REC_PRME);   // every row of the tuple has K components
 #define WIDE_SHAPE(LPT, BB)                                                                                                               \
-    rc = (full_k && m.K == 4 * LPT) ? go(sgd_wide_kernel<MODEL, LPT, BB, false, true>, sgd_wide_kernel<MODEL, LPT, BB, true, true>, LPT, BB) \
-                                    : go(sgd_wide_kernel<MODEL, LPT, BB, false, false>, sgd_wide_kernel<MODEL, LPT, BB, true, false>, LPT, BB)
+    rc = (full_k && m.K == 4 * LPT) ? go(sgd_wide_kernel<MODEL, LPT, BB, false, true>, sgd_wide_kernel<MODEL, LPT, BB, true, true>,               \
+                                         sgd_wide_kernel<MODEL, LPT, BB, false, true, true>, LPT, BB)                                       \
+                                    : go(sgd_wide_kernel<MODEL, LPT, BB, false, false>, sgd_wide_kernel<MODEL, LPT, BB, true, false>,             \
+                                         sgd_wide_kernel<MODEL, LPT, BB, false, false, true>, LPT, BB)
     if (Kmax <= 32) WIDE_SHAPE(8, (R <= 4 ? 2 : 1));
     else if (Kmax <= 64) WIDE_SHAPE(16, 2);
     else if (Kmax <= 128) WIDE_SHAPE(32, 2);
@@ -419,19 +459,33 @@ bool sgd_wide_supported(const DevModel& m, int precision)
 }
 
 // qoff == nullptr: plain mode on the tuples as they come; else owner mode on tuples partitioned by the negative's slice
-// (`slices` of them, qoff[slices + 1])
-int launch_sgd_wide(const DevModel& m, const int4* tuples, const int64_t* qoff, int slices, int64_t n, double lr, int atomic, int flush_at, hipStream_t st)
+// (`slices` of them, qoff[slices + 1]).  sample != nullptr (plain mode only): no tuples are read, the kernel draws step
+// first_step + i of (seed, epoch) for its i-th tuple itself.
+static int wide_launch(const DevModel& m, const int4* tuples, const int64_t* qoff, int slices, int64_t n, double lr, int atomic, int flush_at, hipStream_t st,
+                       const SampleArgs* sample)
 {
     if (n <= 0) return 0;
     switch (m.model) {
-    case REC_BPRMF: return wide_dispatch<REC_BPRMF>(m, tuples, n, lr, atomic, qoff, slices, flush_at, st);
-    case REC_MC: return wide_dispatch<REC_MC>(m, tuples, n, lr, atomic, qoff, slices, flush_at, st);
-    case REC_FPMC: return wide_dispatch<REC_FPMC>(m, tuples, n, lr, atomic, qoff, slices, flush_at, st);
-    case REC_PRME: return wide_dispatch<REC_PRME>(m, tuples, n, lr, atomic, qoff, slices, flush_at, st);
-    case REC_HRM_AVG: return wide_dispatch<REC_HRM_AVG>(m, tuples, n, lr, atomic, qoff, slices, flush_at, st);
-    case REC_HRM_MAX: return wide_dispatch<REC_HRM_MAX>(m, tuples, n, lr, atomic, qoff, slices, flush_at, st);
-    case REC_TRANSREC: return wide_dispatch<REC_TRANSREC>(m, tuples, n, lr, atomic, qoff, slices, flush_at, st);
-    case REC_TRANSREC_L1: return wide_dispatch<REC_TRANSREC_L1>(m, tuples, n, lr, atomic, qoff, slices, flush_at, st);
+    case REC_BPRMF: return wide_dispatch<REC_BPRMF>(m, tuples, n, lr, atomic, qoff, slices, flush_at, st, sample);
+    case REC_MC: return wide_dispatch<REC_MC>(m, tuples, n, lr, atomic, qoff, slices, flush_at, st, sample);
+    case REC_FPMC: return wide_dispatch<REC_FPMC>(m, tuples, n, lr, atomic, qoff, slices, flush_at, st, sample);
+    case REC_PRME: return wide_dispatch<REC_PRME>(m, tuples, n, lr, atomic, qoff, slices, flush_at, st, sample);
+    case REC_HRM_AVG: return wide_dispatch<REC_HRM_AVG>(m, tuples, n, lr, atomic, qoff, slices, flush_at, st, sample);
+    case REC_HRM_MAX: return wide_dispatch<REC_HRM_MAX>(m, tuples, n, lr, atomic, qoff, slices, flush_at, st, sample);
+    case REC_TRANSREC: return wide_dispatch<REC_TRANSREC>(m, tuples, n, lr, atomic, qoff, slices, flush_at, st, sample);
+    case REC_TRANSREC_L1: return wide_dispatch<REC_TRANSREC_L1>(m, tuples, n, lr, atomic, qoff, slices, flush_at, st, sample);
     default: rec_set_error("the wide update kernel is not available for this model"); return -1;
     }
+}
+
+int launch_sgd_wide(const DevModel& m, const int4* tuples, const int64_t* qoff, int slices, int64_t n, double lr, int atomic, int flush_at, hipStream_t st)
+{
+    return wide_launch(m, tuples, qoff, slices, n, lr, atomic, flush_at, st, nullptr);
+}
+
+int launch_sgd_wide_sampled(const DevModel& m, int64_t n, int64_t first_step, uint64_t seed, uint64_t epoch, double lr, int atomic, hipStream_t st)
+{
+    if (m.n_elig <= 0) { rec_set_error("no user (or source item) is eligible for sampling"); return -1; }
+    const SampleArgs sa = {seed, epoch, first_step};
+    return wide_launch(m, nullptr, nullptr, 0, n, lr, atomic, 1, st, &sa);
 }

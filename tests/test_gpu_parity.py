@@ -936,3 +936,4 @@ def test_user_shards_partition_sampling_and_evaluation(model):
         e.close()
     assert got[7] == want[7] and np.allclose(got, want, rtol=1e-12, atol=1e-12)
     full.close()
+

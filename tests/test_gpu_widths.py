@@ -215,3 +215,49 @@ def test_a_query_that_overflows_its_list_is_swept_alone_in_fp64_and_large_biases
     assert mode == 1 and np.array_equal(counts, want)
     assert open2 < 2 * open0 + 100, (open0, open2)
     e.close()
+
+
+@pytest.mark.parametrize("K", [8, 16, 64, 128, 256])
+@pytest.mark.parametrize("model", ["BPRMF", "MC", "FPMC", "PRME", "HRM_avg", "HRM_max", "TransRec", "TransRec_L1"])
+def test_epoch_that_draws_its_own_tuples_applies_the_samplers_tuples(model, K):
+    """"fused_sampler" 1 (the default where the wide kernel applies): the update kernel draws tuple i of the epoch itself.
+    It must be the tuple the sampler reports for that step: with float atomics on every row the result of a launch is the
+    sum of its tuples' deltas whichever kernel drew them, so a fused and an unfused epoch of the same (seed, epoch) agree up
+    to the order of the atomic additions - and both with a Hogwild replay of rec_sample_tuples' output - while another
+    seed gives something else.  What is held exactly is WHICH parameters move (the rows the epoch's tuples name); their
+    values agree but for the rows that two tuples of the launch share (48 tuples on 50 users: some read each other's stale
+    values, differently from run to run)."""
+    if model in ("FPMC", "PRME") and 2 * K > 256:
+        pytest.skip("query width K + KK above 256 is rejected")
+    outs = {}
+    rng = np.random.default_rng(K)
+    W0 = None
+    for name, fused, seed in (("fused", 1, 5), ("unfused", 0, 5), ("replayed", 0, 5), ("other_seed", 1, 6)):
+        g, o, e = _pair(model, K, F32)
+        if W0 is None:
+            W0 = rng.uniform(-0.3, 0.3, o.nw) / np.sqrt(K)
+        e.set_option("update_policy", 0)
+        e.set_option("fused_sampler", fused)
+        e.upload(W0)
+        n = 48
+        before = e.tuples_drawn
+        if name == "replayed":
+            e.sgd_replay(0.05, e.sample_tuples(n, seed=seed, epoch=3), HOGWILD)
+        else:
+            e.sgd_epoch(0.05, n, seed=seed, epoch=3)
+            e.sync()
+            assert e.tuples_drawn - before == n
+        outs[name] = e.download()
+        e.close()
+    W32 = W0.astype(np.float32).astype(np.float64)
+    moved = np.abs(outs["fused"] - W32).max()
+    assert moved > 1e-5
+    touched = outs["fused"] != W32
+    for other in ("unfused", "replayed"):
+        # (HRM_max moves, per component, whichever of the user's and the previous item's value is larger at that moment,
+        # HRM_max.cpp:178-208: which components of a shared row move depends on the race, the rows do not)
+        if model != "HRM_max":
+            assert ((outs[other] != W32) != touched).mean() < 0.02, (model, K, other)     # (a sum of steps can round back to the old value)
+        far = np.abs(outs["fused"] - outs[other])[touched] > 0.05 * moved
+        assert far.mean() < 0.1, (model, K, other, far.mean())
+    assert ((outs["other_seed"] != W32) != touched).mean() > 0.05
