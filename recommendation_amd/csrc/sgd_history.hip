@@ -38,18 +38,21 @@ template <class T> __device__ __forceinline__ T sigm(T x) { return (T)1 / ((T)1 
 template <class T> __device__ __forceinline__ T wsum(T v) { return group_sum<64>(v); }
 
 // Walks the rows tab[seq[h]] for h in [0, hend) (only positions with first[h] set when `first` is given), RIF rows
-// per round.  body(h, item, row components of this lane, delta out) is called for every row; when it returns true
-// and SCATTER is set, the row is updated by the delta (float atomics, or plain stores for hot items / !at_item).
+// per round.  round(h0, ids, it, x, d, upd) is called once per round: lane q < RIF of `ids` holds the item of position
+// h0 + q (-1: position skipped or past the end), it[q] is the same id as a wave-uniform value, x[q] this lane's
+// components of its row (zero where it[q] < 0).  With SCATTER set, the rows q for which it sets upd[q] are updated by
+// d[q] (float atomics, or plain stores for hot items / !at_item).
 //
 // Memory operations retire in order on a wavefront, and a wait for one of them is a wait for everything issued
-// before it.  So a round is laid out as: request the rows (and hot flags) of the next round; request the item
-// ids of the round after that (one load: lane q fetches position h0+q, the ids are read back lane by lane);
-// compute the deltas of this round's rows from registers; issue this round's scatters back to back.  Nothing a
-// scatter needs comes from a load that is younger than the previous round's scatters.
+// before it.  So a round is laid out as: request the rows of the next round (and their hot flags: one load, lane q
+// fetches the flag of row q); request the item ids of the round after that (one load: lane q fetches position
+// h0+q, the ids are read back lane by lane); compute the deltas of this round's rows from registers; issue this
+// round's scatters back to back.  Nothing a scatter needs comes from a load that is younger than the previous
+// round's scatters.
 // A row that round r updates and round r+1 reads again (a repeated item) is read before its update.
-template <int RIF, int EPL, bool SCATTER, class T, class Body>
+template <int RIF, int EPL, bool SCATTER, class T, class Round>
 __device__ __forceinline__ void walk_history(T* tab, const int32_t* seq, const uint8_t* first, const uint8_t* hot, int K, int lane,
-                                             int hend, bool at_item, Body body)
+                                             int hend, bool at_item, Round round)
 {
     static_assert(RIF <= 64, "one lane per position of a round");
     auto load_ids = [&](int h0) {
@@ -58,46 +61,63 @@ __device__ __forceinline__ void walk_history(T* tab, const int32_t* seq, const u
         if (lane < RIF && h < hend) { id = seq[h]; if (first) keep = first[h]; }
         return keep ? id : -1;
     };
-    int itA[RIF], itB[RIF], hotA[RIF], hotB[RIF]; T xA[RIF][EPL], xB[RIF][EPL];
-    auto load_rows = [&](int ids, int (&it)[RIF], int (&hf)[RIF], T (&x)[RIF][EPL]) {
+    int itA[RIF], itB[RIF], hotA = 0, hotB = 0; T xA[RIF][EPL], xB[RIF][EPL];
+    auto load_rows = [&](int ids, int (&it)[RIF], int& hf, T (&x)[RIF][EPL]) {
 #pragma unroll
         for (int q = 0; q < RIF; q++) {
             it[q] = __builtin_amdgcn_readlane(ids, q);
 #pragma unroll
             for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; x[q][j] = (it[q] >= 0 && k < K) ? tab[(int64_t)it[q] * K + k] : (T)0; }
-            hf[q] = (SCATTER && hot && it[q] >= 0) ? (int)hot[it[q]] : 0;
         }
+        hf = (SCATTER && hot && ids >= 0) ? (int)hot[ids] : 0;
     };
-    int idsB = load_ids(0);
-    load_rows(idsB, itA, hotA, xA);
-    idsB = load_ids(RIF);
+    int idsA = load_ids(0);
+    load_rows(idsA, itA, hotA, xA);
+    int idsB = load_ids(RIF);
     for (int h0 = 0; h0 < hend; h0 += RIF) {
         load_rows(idsB, itB, hotB, xB);
-        idsB = load_ids(h0 + 2 * RIF);
+        const int idsN = load_ids(h0 + 2 * RIF);
         T d[RIF][EPL]; bool upd[RIF];
 #pragma unroll
         for (int q = 0; q < RIF; q++) {
+            upd[q] = false;
 #pragma unroll
             for (int j = 0; j < EPL; j++) d[q][j] = 0;
-            upd[q] = itA[q] >= 0 && body(h0 + q, itA[q], xA[q], d[q]);
         }
+        round(h0, idsA, itA, xA, d, upd);
         if constexpr (SCATTER) {
 #pragma unroll
             for (int q = 0; q < RIF; q++) {
                 if (!upd[q]) continue;
                 T* row = tab + (int64_t)itA[q] * K;
-                const bool atc = at_item && !hotA[q];
+                const bool atc = at_item && !__builtin_amdgcn_readlane(hotA, q);
 #pragma unroll
                 for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; if (k < K) scat(row + k, d[q][j], xA[q][j], atc); }
             }
         }
 #pragma unroll
         for (int q = 0; q < RIF; q++) {
-            itA[q] = itB[q]; hotA[q] = hotB[q];
+            itA[q] = itB[q];
 #pragma unroll
             for (int j = 0; j < EPL; j++) xA[q][j] = xB[q][j];
         }
+        hotA = hotB; idsA = idsB; idsB = idsN;
     }
+}
+
+// The items of a group of G tuples whose rows need more than the common step of pass 2 (the positive, the negative
+// and the up to Ls short-term / path items of every tuple), one per lane: slot g * (Ls + 2) + r.
+template <int G>
+__device__ __forceinline__ int special_items(const int (&shortl)[G], const int (&pos)[G], const int (&neg)[G], int Ls, int lane)
+{
+    int spec = -2;
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const int r = lane - g * (Ls + 2);
+        const int v = __shfl(shortl[g], r & 63, 64);
+        if (r >= 0 && r < Ls + 2) spec = r < Ls ? v : (r == Ls ? pos[g] : neg[g]);
+    }
+    return spec;
 }
 
 // (f32, K <= 64, one or two tuples per walk: held to 128 registers, four wavefronts per SIMD - REBUS with two tuples per
@@ -154,7 +174,6 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
             int pos[G], neg[G], np[G], prevl[G];   // prevl: lane ind holds the ind-th previous item of tuple g
             int hp[G], hn[G];                      // hot flags of pos / neg, fetched with their rows
             T vp[G][EPL], vn[G][EPL], sp[G][EPL], sn[G][EPL];
-            double spd[G][EPL], snd[G][EPL];   // the sums over the history in fp64 whatever the tables' type (see REBUS below)
 #pragma unroll
             for (int g = 0; g < G; g++) {
                 const bool valid = g < ng;
@@ -166,25 +185,46 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
                 hp[g] = (valid && (at_item || at_bias)) ? m.hot[pos[g]] : 0; hn[g] = (valid && (at_item || at_bias)) ? m.hot[neg[g]] : 0;
 #pragma unroll
                 for (int j = 0; j < EPL; j++) {
-                    const int k = lane + 64 * j; sp[g][j] = sn[g][j] = 0; spd[g][j] = snd[g][j] = 0;
+                    const int k = lane + 64 * j; sp[g][j] = sn[g][j] = 0;
                     vp[g][j] = (valid && k < K) ? V[(int64_t)pos[g] * K + k] : (T)0;
                     vn[g][j] = (valid && k < K) ? V[(int64_t)neg[g] * K + k] : (T)0;
                 }
             }
-            // pass 1: history sums, Fossil.cpp:140-153
-            int cp[G], cn[G];
+            // pass 1: history sums, Fossil.cpp:140-153.  Every tuple of the group sums the whole sequence except the
+            // positions that hold its positive / its negative: ONE sum over all positions (in fp64 whatever the tables'
+            // type, see REBUS below), the occurrences of each tuple's two items counted on the way (lane q of `ids`
+            // against a wave-uniform id: one compare per round and item) and their rows taken out afterwards.
+            double S[EPL];
+#pragma unroll
+            for (int j = 0; j < EPL; j++) S[j] = 0;
+            int cp[G], cn[G];   // occurrences of pos / neg first, then the lengths of the two sums
 #pragma unroll
             for (int g = 0; g < G; g++) cp[g] = cn[g] = 0;
-            walk_history<RIF, EPL, false>(Ui, seq, nullptr, nullptr, K, lane, nu, false, [&](int, int c, const T (&x)[EPL], T (&)[EPL]) {
+            walk_history<RIF, EPL, false>(Ui, seq, nullptr, nullptr, K, lane, nu, false,
+                [&](int, int ids, const int (&)[RIF], const T (&x)[RIF][EPL], T (&)[RIF][EPL], bool (&)[RIF]) {
 #pragma unroll
                 for (int g = 0; g < G; g++) {
-                    const bool a = c != pos[g], b = c != neg[g];
-                    cp[g] += a; cn[g] += b;
-#pragma unroll
-                    for (int j = 0; j < EPL; j++) { spd[g][j] += a ? (double)x[j] : 0.0; snd[g][j] += b ? (double)x[j] : 0.0; }
+                    cp[g] += __popcll(__ballot(ids == pos[g] && ids >= 0));
+                    cn[g] += __popcll(__ballot(ids == neg[g] && ids >= 0));
                 }
-                return false;
+#pragma unroll
+                for (int q = 0; q < RIF; q++)
+#pragma unroll
+                    for (int j = 0; j < EPL; j++) S[j] += (double)x[q][j];
             });
+            double spd[G][EPL], snd[G][EPL];
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                const int op = cp[g], on = cn[g];
+                cp[g] = nu - op; cn[g] = nu - on;
+#pragma unroll
+                for (int j = 0; j < EPL; j++) {
+                    const int k = lane + 64 * j;
+                    spd[g][j] = snd[g][j] = S[j];
+                    if (g < ng && op > 0 && k < K) spd[g][j] -= (double)op * (double)Ui[(int64_t)pos[g] * K + k];
+                    if (g < ng && on > 0 && k < K) snd[g][j] -= (double)on * (double)Ui[(int64_t)neg[g] * K + k];
+                }
+            }
             // short-term weights: lane ind holds WT[ind] + WTu[u][ind] (Fossil) / lane 0 alpha + alpha_u[u] (FossilSimple)
             T wt_g = 0, wt_u = 0;
             if (lane < (SIMPLE ? 1 : L)) {
@@ -243,10 +283,38 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
                 T* wu = SIMPLE ? (T*)m.tab[FS_ALPHA_U] + u : (T*)m.tab[FO_WTU] + (int64_t)u * L + lane;
                 scat(wu, user_delta, wt_u, at_user);
             }
-            // pass 2: every history row once for the whole group, Fossil.cpp:209-247 / FossilSimple.cpp:198-226
+            // pass 2: every history row once for the whole group, Fossil.cpp:209-247 / FossilSimple.cpp:198-226.
+            // A row that is none of the group's positives, negatives or short-term items receives the same step from
+            // every tuple - deri * (wp * Vp - wn * Vn), summed once per group - and its own regulariser term: one
+            // multiply-add per row.  The others (found by comparing the row's id with the group's list of such items,
+            // one per lane) go through the per-tuple case analysis.
             const T wt0 = __shfl(wt, 0, 64);
             const T reg = lam * (T)ng;
-            walk_history<RIF, EPL, true>(Ui, seq, nullptr, at_item ? m.hot : nullptr, K, lane, nu, at_item, [&](int, int c, const T (&x)[EPL], T (&d)[EPL]) {
+            const int Ls = SIMPLE ? 1 : L;
+            const bool listed = G * (Ls + 2) <= 64;
+            const int spec = special_items<G>(prevl, pos, neg, Ls, lane);
+            T lrD[EPL];
+#pragma unroll
+            for (int j = 0; j < EPL; j++) {
+                T D = 0;
+#pragma unroll
+                for (int g = 0; g < G; g++) D += deri[g] * (wp[g] * vp[g][j] - wn[g] * vn[g][j]);   // deri = wp = wn = 0 past the group's end
+                lrD[j] = lr * D;
+            }
+            const T lrreg = lr * reg;
+            walk_history<RIF, EPL, true>(Ui, seq, nullptr, at_item ? m.hot : nullptr, K, lane, nu, at_item,
+                [&](int, int, const int (&it)[RIF], const T (&x)[RIF][EPL], T (&dd)[RIF][EPL], bool (&upd)[RIF]) {
+#pragma unroll
+              for (int q = 0; q < RIF; q++) {
+                const int c = it[q];
+                if (c < 0) continue;
+                upd[q] = true;
+                T (&d)[EPL] = dd[q];
+                if (listed && __ballot(spec == c) == 0) {
+#pragma unroll
+                    for (int j = 0; j < EPL; j++) d[j] = lrD[j] - lrreg * x[q][j];
+                    continue;
+                }
 #pragma unroll
                 for (int g = 0; g < G; g++) {
                     const uint64_t hit = __ballot(prevl[g] == c);
@@ -262,8 +330,8 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
                     for (int j = 0; j < EPL; j++) d[j] += cpz * vp[g][j] - cnz * vn[g][j];
                 }
 #pragma unroll
-                for (int j = 0; j < EPL; j++) d[j] = lr * (d[j] - reg * x[j]);
-                return true;
+                for (int j = 0; j < EPL; j++) d[j] = lr * (d[j] - reg * x[q][j]);
+              }
             });
             // Fossil.cpp:249-252
 #pragma unroll
@@ -288,9 +356,6 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
             int tpos[G], pos[G], neg[G], np[G], pathl[G];   // pathl / etal: lane r holds the r-th item of tuple g's matched path and its weight
             T etal[G];
             T pp[G][EPL], pn[G][EPL], sp[G][EPL], sn[G][EPL];
-            // the sums over the history are kept in fp64 whatever the tables' type: a history of thousands of items summed
-            // in f32 is off by ~1e-4 of the sum, which the two squared distances then turn into an error of that size in x_uij
-            double spd[G][EPL], snd[G][EPL];
             int tmax = 0;
 #pragma unroll
             for (int g = 0; g < G; g++) {
@@ -309,27 +374,66 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
                 tmax = tpos[g] > tmax ? tpos[g] : tmax;
 #pragma unroll
                 for (int j = 0; j < EPL; j++) {
-                    const int k = lane + 64 * j; spd[g][j] = snd[g][j] = 0;
+                    const int k = lane + 64 * j;
                     pp[g][j] = (valid && k < K) ? P[(int64_t)pos[g] * K + k] : (T)0;
                     pn[g][j] = (valid && k < K) ? P[(int64_t)neg[g] * K + k] : (T)0;
                 }
             }
+            // pass 1.  Tuple g sums the kept rows of positions [0, tpos[g]) except its positive's and its negative's: ONE
+            // running sum over the walk, copied for tuple g where the walk passes tpos[g]; the two rows are taken out
+            // afterwards (they are in registers already), what each position's id says about each tuple (inside its
+            // prefix? its positive? its negative?) is asked once per round, lane q of `ids` against wave-uniform values.
+            // The sums are kept in fp64 whatever the tables' type: a history of thousands of items summed in f32 is off
+            // by ~1e-4 of the sum, which the two squared distances then turn into an error of that size in x_uij.
+            double S[EPL], snap[G][EPL];
+#pragma unroll
+            for (int j = 0; j < EPL; j++) {
+                S[j] = 0;
+#pragma unroll
+                for (int g = 0; g < G; g++) snap[g][j] = 0;
+            }
             int cp[G], cn[G]; unsigned pos_in = 0, neg_in = 0;
 #pragma unroll
             for (int g = 0; g < G; g++) cp[g] = cn[g] = 0;
-            walk_history<RIF, EPL, false>(P, seq, fo, nullptr, K, lane, tmax, false, [&](int h, int c, const T (&x)[EPL], T (&)[EPL]) {
+            walk_history<RIF, EPL, false>(P, seq, fo, nullptr, K, lane, tmax, false,
+                [&](int h0, int ids, const int (&)[RIF], const T (&x)[RIF][EPL], T (&)[RIF][EPL], bool (&)[RIF]) {
+                bool edge = false;   // a prefix ends inside this round
 #pragma unroll
                 for (int g = 0; g < G; g++) {
-                    const bool in = h < tpos[g];
-                    const bool a = in && c != pos[g], b = in && c != neg[g];
-                    cp[g] += a; cn[g] += b;
-                    if (in && !a) pos_in |= 1u << g;
-                    if (in && !b) neg_in |= 1u << g;
-#pragma unroll
-                    for (int j = 0; j < EPL; j++) { spd[g][j] += a ? (double)x[j] : 0.0; snd[g][j] += b ? (double)x[j] : 0.0; }
+                    const bool in = h0 + lane < tpos[g] && ids >= 0;
+                    cp[g] += __popcll(__ballot(in));
+                    if (__ballot(in && ids == pos[g]) != 0) pos_in |= 1u << g;
+                    if (__ballot(in && ids == neg[g]) != 0) neg_in |= 1u << g;
+                    edge |= (unsigned)(tpos[g] - h0) < (unsigned)RIF;
                 }
-                return false;
+                if (!edge) {
+#pragma unroll
+                    for (int q = 0; q < RIF; q++)
+#pragma unroll
+                        for (int j = 0; j < EPL; j++) S[j] += (double)x[q][j];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < RIF; q++) {
+#pragma unroll
+                        for (int g = 0; g < G; g++)
+                            if (tpos[g] == h0 + q) {
+#pragma unroll
+                                for (int j = 0; j < EPL; j++) snap[g][j] = S[j];
+                            }
+#pragma unroll
+                        for (int j = 0; j < EPL; j++) S[j] += (double)x[q][j];
+                    }
+                }
             });
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                if (tpos[g] == tmax) {   // (a prefix that ends where the walk does: the rows past it were read as zeros)
+#pragma unroll
+                    for (int j = 0; j < EPL; j++) snap[g][j] = S[j];
+                }
+                const int kept = cp[g];
+                cp[g] = kept - (int)((pos_in >> g) & 1); cn[g] = kept - (int)((neg_in >> g) & 1);
+            }
             T wp[G], wn[G], deri[G];
             T bp[G], bn[G];     // lane 0: the biases as the group found them
 #pragma unroll
@@ -353,7 +457,8 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
                 double qd = 0;
 #pragma unroll
                 for (int j = 0; j < EPL; j++) {
-                    const double dp = wpd * spd[g][j] + (double)sl[j] - (double)pp[g][j], dn = wnd * snd[g][j] + (double)sl[j] - (double)pn[g][j];
+                    const double spd = snap[g][j] - (((pos_in >> g) & 1) ? (double)pp[g][j] : 0.0), snd = snap[g][j] - (((neg_in >> g) & 1) ? (double)pn[g][j] : 0.0);
+                    const double dp = wpd * spd + (double)sl[j] - (double)pp[g][j], dn = wnd * snd + (double)sl[j] - (double)pn[g][j];
                     sp[g][j] = (T)dp; sn[g][j] = (T)dn;
                     qd += dn * dn - dp * dp;
                 }
@@ -365,7 +470,44 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
                     scat(beta + neg[g], lr * (deri[g] - breg * bneg), bneg, at_bias && !hn[g]);    // [10]
                 }
             }
-            walk_history<RIF, EPL, true>(P, seq, fo, at_item ? m.hot : nullptr, K, lane, tmax, at_item, [&](int h, int c, const T (&x)[EPL], T (&d)[EPL]) {
+            // pass 2.  A kept row of position h that is none of the group's positives, negatives or path items receives
+            // deri * (wn * dist_neg - wp * dist_pos) from every tuple whose prefix holds h, and its own regulariser term
+            // once per such tuple: with that sum formed once per stretch of positions between two prefix ends, one
+            // multiply-add per row.  The other rows (found by comparing the row's id with the group's list of such
+            // items, one per lane) go through the per-tuple case analysis.
+            const bool listed = G * (L + 2) <= 64;
+            const int spec = special_items<G>(pathl, pos, neg, L, lane);
+            T lrD[EPL], lrreg = 0; int stretch_end = 0;   // the common step of positions [.., stretch_end)
+            auto begin_stretch = [&](int h) {
+                int nact = 0; stretch_end = 0x7fffffff;
+#pragma unroll
+                for (int j = 0; j < EPL; j++) lrD[j] = 0;
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    if (h >= tpos[g]) continue;
+                    nact++; stretch_end = tpos[g] < stretch_end ? tpos[g] : stretch_end;
+#pragma unroll
+                    for (int j = 0; j < EPL; j++) lrD[j] += deri[g] * (wn[g] * sn[g][j] - wp[g] * sp[g][j]);
+                }
+#pragma unroll
+                for (int j = 0; j < EPL; j++) lrD[j] *= lr;
+                lrreg = lr * lam * (T)nact;
+            };
+            begin_stretch(0);
+            walk_history<RIF, EPL, true>(P, seq, fo, at_item ? m.hot : nullptr, K, lane, tmax, at_item,
+                [&](int h0, int, const int (&it)[RIF], const T (&x)[RIF][EPL], T (&dd)[RIF][EPL], bool (&upd)[RIF]) {
+#pragma unroll
+              for (int q = 0; q < RIF; q++) {
+                const int c = it[q], h = h0 + q;
+                if (c < 0) continue;
+                T (&d)[EPL] = dd[q];
+                if (h >= stretch_end) begin_stretch(h);
+                if (listed && __ballot(spec == c) == 0) {
+#pragma unroll
+                    for (int j = 0; j < EPL; j++) d[j] = lrD[j] - lrreg * x[q][j];
+                    upd[q] = true;
+                    continue;
+                }
                 int nact = 0;
 #pragma unroll
                 for (int g = 0; g < G; g++) {
@@ -386,11 +528,12 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
 #pragma unroll
                     for (int j = 0; j < EPL; j++) d[j] += a * sp[g][j] + b * sn[g][j];
                 }
-                if (nact == 0) return false;
+                if (nact == 0) continue;
                 const T reg = lam * (T)nact;
 #pragma unroll
-                for (int j = 0; j < EPL; j++) d[j] = lr * (d[j] - reg * x[j]);
-                return true;
+                for (int j = 0; j < EPL; j++) d[j] = lr * (d[j] - reg * x[q][j]);
+                upd[q] = true;
+              }
             });
 #pragma unroll
             for (int g = 0; g < G; g++) {
