@@ -193,6 +193,7 @@ def main():
     ap.add_argument("--overlap", type=int, default=0)
     ap.add_argument("--share-positive", type=int, default=0, help="share_positive of the group models (1, 2); 0 = engine default")
     ap.add_argument("--share-negative", type=int, default=0, help="share_negative of the group models (1, 2); 0 = engine default")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="any other engine option (rec_set_option), applied last")
     ap.add_argument("--user-batch", type=int, default=0, help="user_batch of the history models (1, 2, 4, 8); 0 = engine default")
     ap.add_argument("--owner", type=int, default=-1, help="owner_neg: negatives' deltas summed in LDS by the workgroup that owns their slice of the catalog (0, 1); -1 = engine default")
     ap.add_argument("--part-tile", type=int, default=0, help="tuples the owner mode's partition sorts in LDS at a time (0 = engine default)")
@@ -301,6 +302,9 @@ def main():
         eng.set_option("part_tile", args.part_tile)
     if mode["group"] or mode["pos_share"] == 2 or args.overlap:
         mode["owner"] = 0   # the engine falls back to the plain kernel in these modes
+    for kv in args.opt:
+        k, v = kv.split("=")
+        eng.set_option(k, int(v)); mode[k] = int(v)
     eng.set_option("profile", 1)
     steps_per_epoch = eng.steps_per_epoch
     my_steps = steps_per_epoch // world

@@ -34,74 +34,128 @@ __device__ __forceinline__ int64_t uni(int64_t v)
 {
     return (int64_t)(((uint64_t)(uint32_t)uni((int)((uint64_t)v >> 32)) << 32) | (uint32_t)uni((int)(uint32_t)v));
 }
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 template <class T> __device__ __forceinline__ T sigm(T x) { return (T)1 / ((T)1 + rexp(x)); }
 template <class T> __device__ __forceinline__ T wsum(T v) { return group_sum<64>(v); }
 
-// Walks the rows tab[seq[h]] for h in [0, hend) (only positions with first[h] set when `first` is given), RIF rows
-// per round.  round(h0, ids, it, x, d, upd) is called once per round: lane q < RIF of `ids` holds the item of position
-// h0 + q (-1: position skipped or past the end), it[q] is the same id as a wave-uniform value, x[q] this lane's
-// components of its row (zero where it[q] < 0).  With SCATTER set, the rows q for which it sets upd[q] are updated by
-// d[q] (float atomics, or plain stores for hot items / !at_item).
+// Walks the rows tab[seq[h]] for h in [0, hend) (only positions with first[h] set when FIRST), RIF rows per round.
+// round(h0, ids, it, x) is called once per round: lane q < RIF of `ids` holds the item of position h0 + q (-1:
+// position skipped or past the end), it[q] is the same id as a wave-uniform value, x[q] this lane's components of its
+// row (UNDEFINED where it[q] < 0, and on lanes whose component is past K: the caller clears what it sums on those
+// lanes).  With SCATTER set it returns two bit masks over the rows of the round: the rows of the low 16 bits are
+// updated by the common step cD - creg * x (float atomics, or plain stores for hot items / !at_item), the rows of the
+// high 16 bits are handed one by one to special(h, item, row components, delta out), which returns whether to update
+// the row; after(h0) runs when the round's rows have been dealt with (it may change cD / creg for the next round).
 //
-// Memory operations retire in order on a wavefront, and a wait for one of them is a wait for everything issued
-// before it.  So a round is laid out as: request the rows of the next round (and their hot flags: one load, lane q
-// fetches the flag of row q); request the item ids of the round after that (one load: lane q fetches position
-// h0+q, the ids are read back lane by lane); compute the deltas of this round's rows from registers; issue this
-// round's scatters back to back.  Nothing a scatter needs comes from a load that is younger than the previous
-// round's scatters.
-// A row that round r updates and round r+1 reads again (a repeated item) is read before its update.
-template <int RIF, int EPL, bool SCATTER, class T, class Round>
+// Memory operations retire in order on a wavefront, a wait is "until at most N are outstanding", and the compiler can
+// only count the operations that are certain to have been issued.  So every load of the loop is unconditional
+// (positions past the end re-read the last one, skipped positions read row 0, lanes past K the last component) and a
+// round is laid out as: request the item ids of the fifth round from here (one load: lane q fetches position h0+q,
+// the ids are read back lane by lane); request the rows (and hot flags: one load, lane q fetches the flag of row q) of
+// the round after the next; compute this round's deltas from registers; issue this round's scatters back to back.
+// The rows a round computes with were requested two rounds earlier, and nothing a scatter needs comes from a load
+// that is younger than the previous round's scatters.
+// A row that round r updates and rounds r+1 / r+2 read again (a repeated item) is read before its update.
+template <int RIF, int EPL, bool SCATTER, bool FIRST, class T, class Round, class Special, class After>
 __device__ __forceinline__ void walk_history(T* tab, const int32_t* seq, const uint8_t* first, const uint8_t* hot, int K, int lane,
-                                             int hend, bool at_item, Round round)
+                                             int hend, bool at_item, const T (&cD)[EPL], const T& creg, Round round, Special special, After after)
 {
-    static_assert(RIF <= 64, "one lane per position of a round");
-    auto load_ids = [&](int h0) {
-        const int h = h0 + lane;
-        int id = -1, keep = 1;
-        if (lane < RIF && h < hend) { id = seq[h]; if (first) keep = first[h]; }
-        return keep ? id : -1;
+    static_assert(RIF <= 16, "one lane per position of a round, two masks of one bit per row");
+    if (hend <= 0) return;
+    uint32_t kc[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; kc[j] = (uint32_t)(k < K ? k : K - 1); }
+    const uint32_t row_bytes = (uint32_t)K * (uint32_t)sizeof(T);
+    auto load_ids = [&](int h0, int& id, int& keep) {
+        int h = h0 + lane; h = h < hend ? h : hend - 1;
+        id = seq[h]; keep = FIRST ? (int)first[h] : 1;
     };
-    int itA[RIF], itB[RIF], hotA = 0, hotB = 0; T xA[RIF][EPL], xB[RIF][EPL];
-    auto load_rows = [&](int ids, int (&it)[RIF], int& hf, T (&x)[RIF][EPL]) {
+    auto resolve = [&](int h0, int id, int keep) { return (lane < RIF && h0 + lane < hend && keep != 0) ? id : -1; };
+    auto load_rows = [&](int ids, int& hf, T (&x)[RIF][EPL]) {
+        const int idc = ids > 0 ? ids : 0;
+        const uint64_t ob = (uint64_t)(uint32_t)idc * row_bytes;   // lane q: byte offset of row q
+        const int olo = (int)(uint32_t)ob, ohi = (int)(uint32_t)(ob >> 32);
 #pragma unroll
         for (int q = 0; q < RIF; q++) {
-            it[q] = __builtin_amdgcn_readlane(ids, q);
+            const uint64_t o = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(ohi, q) << 32) | (uint32_t)__builtin_amdgcn_readlane(olo, q);
+            const T* row = (const T*)((const char*)tab + o);
 #pragma unroll
-            for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; x[q][j] = (it[q] >= 0 && k < K) ? tab[(int64_t)it[q] * K + k] : (T)0; }
+            for (int j = 0; j < EPL; j++) x[q][j] = row[kc[j]];
         }
-        hf = (SCATTER && hot && ids >= 0) ? (int)hot[ids] : 0;
+        hf = SCATTER ? (int)hot[idc] : 0;
     };
-    int idsA = load_ids(0);
-    load_rows(idsA, itA, hotA, xA);
-    int idsB = load_ids(RIF);
-    for (int h0 = 0; h0 < hend; h0 += RIF) {
-        load_rows(idsB, itB, hotB, xB);
-        const int idsN = load_ids(h0 + 2 * RIF);
-        T d[RIF][EPL]; bool upd[RIF];
+    // Round R keeps its rows in buffer R % 3 and its raw ids in slot R % 3; the loop is unrolled three times so that no
+    // register that a load is still going to write has to be moved (a move would wait for the load).  Ids are
+    // requested BEFORE the rows requested in the same round: waiting for them three rounds later then waits for no
+    // row that was requested after them.
+    int id0, id1, id2 = -1, hot0 = 0, hot1 = 0, hot2 = 0, rid0, keep0, rid1, keep1, rid2, keep2;
+    T x0[RIF][EPL], x1[RIF][EPL], x2[RIF][EPL];
+    auto stage = [&](int h0, int idCur, int hotCur, const T (&xCur)[RIF][EPL], int& idLd, int& hotLd, T (&xLd)[RIF][EPL], int& rid, int& keep) {
+        idLd = resolve(h0 + 2 * RIF, rid, keep);
+        load_ids(h0 + 5 * RIF, rid, keep);
+        load_rows(idLd, hotLd, xLd);
+        int it[RIF];
 #pragma unroll
-        for (int q = 0; q < RIF; q++) {
-            upd[q] = false;
-#pragma unroll
-            for (int j = 0; j < EPL; j++) d[q][j] = 0;
-        }
-        round(h0, idsA, itA, xA, d, upd);
+        for (int q = 0; q < RIF; q++) it[q] = __builtin_amdgcn_readlane(idCur, q);
+        unsigned masks = round(h0, idCur, it, xCur);
         if constexpr (SCATTER) {
+            // (this round's rows are needed from here on whatever the masks say: asking for them once, outside the
+            // conditional code below, keeps the compiler from waiting for EVERY outstanding load in front of the loop
+            // over the special rows)
+#pragma unroll
+            for (int q = 0; q < RIF; q++)
+#pragma unroll
+                for (int j = 0; j < EPL; j++) asm volatile("" :: "v"(xCur[q][j]));
 #pragma unroll
             for (int q = 0; q < RIF; q++) {
-                if (!upd[q]) continue;
-                T* row = tab + (int64_t)itA[q] * K;
-                const bool atc = at_item && !__builtin_amdgcn_readlane(hotA, q);
+                if (!((masks >> q) & 1)) continue;
+                T* row = tab + (int64_t)it[q] * K;
+                const bool atc = at_item && !__builtin_amdgcn_readlane(hotCur, q);
 #pragma unroll
-                for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; if (k < K) scat(row + k, d[q][j], xA[q][j], atc); }
+                for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; if (k < K) scat(row + k, cD[j] - creg * xCur[q][j], xCur[q][j], atc); }
             }
-        }
+            unsigned sm = (unsigned)uni((int)(masks >> 16));
+            while (sm) {
+                const int q = __builtin_ctz(sm); sm &= sm - 1;
+                const int c = __builtin_amdgcn_readlane(idCur, q);
+                T xs[EPL], ds[EPL];
 #pragma unroll
-        for (int q = 0; q < RIF; q++) {
-            itA[q] = itB[q];
+                for (int j = 0; j < EPL; j++) {
+                    // row q of the round, q known at run time only: masked together word by word (a chain of selects is
+                    // turned into an indexed load from a copy of the rows in scratch memory)
+                    uint32_t w[sizeof(T) / 4];
 #pragma unroll
-            for (int j = 0; j < EPL; j++) xA[q][j] = xB[q][j];
+                    for (unsigned i = 0; i < sizeof(T) / 4; i++) w[i] = 0;
+#pragma unroll
+                    for (int qq = 0; qq < RIF; qq++) {
+                        uint32_t v[sizeof(T) / 4];
+                        __builtin_memcpy(v, &xCur[qq][j], sizeof(T));
+                        const uint32_t msk = q == qq ? ~0u : 0u;
+#pragma unroll
+                        for (unsigned i = 0; i < sizeof(T) / 4; i++) w[i] |= v[i] & msk;
+                    }
+                    __builtin_memcpy(&xs[j], w, sizeof(T));
+                    ds[j] = 0;
+                }
+                if (!special(h0 + q, c, xs, ds)) continue;
+                T* row = tab + (int64_t)c * K;
+                const bool atc = at_item && !__builtin_amdgcn_readlane(hotCur, q);
+#pragma unroll
+                for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; if (k < K) scat(row + k, ds[j], xs[j], atc); }
+            }
+            after(h0);
         }
-        hotA = hotB; idsA = idsB; idsB = idsN;
+    };
+    load_ids(0, rid0, keep0); load_ids(RIF, rid1, keep1);
+    id0 = resolve(0, rid0, keep0); id1 = resolve(RIF, rid1, keep1);
+    load_ids(2 * RIF, rid2, keep2); load_ids(3 * RIF, rid0, keep0); load_ids(4 * RIF, rid1, keep1);
+    load_rows(id0, hot0, x0); load_rows(id1, hot1, x1);
+    for (int h0 = 0; h0 < hend; h0 += 3 * RIF) {
+        stage(h0, id0, hot0, x0, id2, hot2, x2, rid2, keep2);
+        if (h0 + RIF >= hend) break;
+        stage(h0 + RIF, id1, hot1, x1, id0, hot0, x0, rid0, keep0);
+        if (h0 + 2 * RIF >= hend) break;
+        stage(h0 + 2 * RIF, id2, hot2, x2, id1, hot1, x1, rid1, keep1);
     }
 }
 
@@ -190,6 +244,23 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
                     vn[g][j] = (valid && k < K) ? V[(int64_t)neg[g] * K + k] : (T)0;
                 }
             }
+            // The rows the step needs beside the history - those of each tuple's short-term items, and the positive's own
+            // row in the history table - are requested here, all at once, and used after pass 1: asked for where they
+            // are used they cost one memory round trip each, one after the other.
+            constexpr int LR = 3;   // short-term rows per tuple held in registers; longer contexts fetch the rest in place
+            T px[G][LR][EPL], uip[G][EPL];
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                const int cpos = pos[g] > 0 ? pos[g] : 0;
+#pragma unroll
+                for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; uip[g][j] = k < K ? Ui[(int64_t)cpos * K + k] : (T)0; }
+#pragma unroll
+                for (int ind = 0; ind < LR; ind++) {
+                    const int c = ind < np[g] ? uni(__shfl(prevl[g], ind, 64)) : cpos;
+#pragma unroll
+                    for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; px[g][ind][j] = k < K ? Ui[(int64_t)c * K + k] : (T)0; }
+                }
+            }
             // pass 1: history sums, Fossil.cpp:140-153.  Every tuple of the group sums the whole sequence except the
             // positions that hold its positive / its negative: ONE sum over all positions (in fp64 whatever the tables'
             // type, see REBUS below), the occurrences of each tuple's two items counted on the way (lane q of `ids`
@@ -200,18 +271,26 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
             int cp[G], cn[G];   // occurrences of pos / neg first, then the lengths of the two sums
 #pragma unroll
             for (int g = 0; g < G; g++) cp[g] = cn[g] = 0;
-            walk_history<RIF, EPL, false>(Ui, seq, nullptr, nullptr, K, lane, nu, false,
-                [&](int, int ids, const int (&)[RIF], const T (&x)[RIF][EPL], T (&)[RIF][EPL], bool (&)[RIF]) {
+            auto no_special = [](int, int, const T (&)[EPL], T (&)[EPL]) { return false; };
+            auto no_after = [](int) {};
+            const T none[EPL] = {}, zero = 0;
+            walk_history<RIF, EPL, false, false>(Ui, seq, nullptr, m.hot, K, lane, nu, false, none, zero,
+                [&](int, int ids, const int (&it)[RIF], const T (&x)[RIF][EPL]) {
 #pragma unroll
                 for (int g = 0; g < G; g++) {
-                    cp[g] += __popcll(__ballot(ids == pos[g] && ids >= 0));
-                    cn[g] += __popcll(__ballot(ids == neg[g] && ids >= 0));
+                    cp[g] += __popcll(ballot64(ids == pos[g] && ids >= 0));
+                    cn[g] += __popcll(ballot64(ids == neg[g] && ids >= 0));
                 }
 #pragma unroll
-                for (int q = 0; q < RIF; q++)
+                for (int q = 0; q < RIF; q++) {
+                    if (it[q] < 0) continue;
 #pragma unroll
                     for (int j = 0; j < EPL; j++) S[j] += (double)x[q][j];
-            });
+                }
+                return 0u;
+            }, no_special, no_after);
+#pragma unroll
+            for (int j = 0; j < EPL; j++) if (lane + 64 * j >= K) S[j] = 0;
             double spd[G][EPL], snd[G][EPL];
 #pragma unroll
             for (int g = 0; g < G; g++) {
@@ -221,7 +300,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
                 for (int j = 0; j < EPL; j++) {
                     const int k = lane + 64 * j;
                     spd[g][j] = snd[g][j] = S[j];
-                    if (g < ng && op > 0 && k < K) spd[g][j] -= (double)op * (double)Ui[(int64_t)pos[g] * K + k];
+                    if (g < ng) spd[g][j] -= (double)op * (double)uip[g][j];
                     if (g < ng && on > 0 && k < K) snd[g][j] -= (double)on * (double)Ui[(int64_t)neg[g] * K + k];
                 }
             }
@@ -244,23 +323,31 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
 #pragma unroll
                 for (int j = 0; j < EPL; j++) { sp[g][j] = (T)((double)wp[g] * spd[g][j]); sn[g][j] = (T)((double)wn[g] * snd[g][j]); }
                 T grad_mine = 0;
-                for (int ind = 0; ind < np[g]; ind++) {
+                auto short_term = [&](int ind, const T (&x)[EPL]) {
                     const int c = uni(__shfl(prevl[g], ind, 64));
                     const T w = __shfl(wt, ind, 64);
                     T d1 = 0, d2 = 0;
 #pragma unroll
                     for (int j = 0; j < EPL; j++) {
-                        const int k = lane + 64 * j;
-                        const T x = k < K ? Ui[(int64_t)c * K + k] : (T)0;
                         // FossilSimple adds the short-term term on both sides unconditionally (FossilSimple.cpp:180-181)
-                        if (SIMPLE || c != pos[g]) sp[g][j] += w * x;
-                        if (SIMPLE || c != neg[g]) sn[g][j] += w * x;
-                        d1 += x * vp[g][j]; d2 += x * vn[g][j];
+                        if (SIMPLE || c != pos[g]) sp[g][j] += w * x[j];
+                        if (SIMPLE || c != neg[g]) sn[g][j] += w * x[j];
+                        d1 += x[j] * vp[g][j]; d2 += x[j] * vn[g][j];
                     }
                     d1 = wsum(d1); d2 = wsum(d2);
                     // Fossil.cpp:194-206 (three cases); FossilSimple.cpp:195-196 (always the difference)
                     const T gI = (SIMPLE || (c != pos[g] && c != neg[g])) ? d1 - d2 : (c != pos[g] ? d1 : -d2);
                     if (lane == ind) grad_mine = gI;
+                };
+#pragma unroll
+                for (int ind = 0; ind < LR; ind++)
+                    if (ind < np[g]) short_term(ind, px[g][ind]);
+                for (int ind = LR; ind < np[g]; ind++) {
+                    const int c = uni(__shfl(prevl[g], ind, 64));
+                    T x[EPL];
+#pragma unroll
+                    for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; x[j] = k < K ? Ui[(int64_t)c * K + k] : (T)0; }
+                    short_term(ind, x);
                 }
                 T s1 = 0, s2 = 0;
 #pragma unroll
@@ -302,22 +389,21 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
                 lrD[j] = lr * D;
             }
             const T lrreg = lr * reg;
-            walk_history<RIF, EPL, true>(Ui, seq, nullptr, at_item ? m.hot : nullptr, K, lane, nu, at_item,
-                [&](int, int, const int (&it)[RIF], const T (&x)[RIF][EPL], T (&dd)[RIF][EPL], bool (&upd)[RIF]) {
+            walk_history<RIF, EPL, true, false>(Ui, seq, nullptr, m.hot, K, lane, nu, at_item, lrD, lrreg,
+                [&](int, int, const int (&it)[RIF], const T (&)[RIF][EPL]) {
+                unsigned common = 0, sm = 0;
 #pragma unroll
-              for (int q = 0; q < RIF; q++) {
-                const int c = it[q];
-                if (c < 0) continue;
-                upd[q] = true;
-                T (&d)[EPL] = dd[q];
-                if (listed && __ballot(spec == c) == 0) {
-#pragma unroll
-                    for (int j = 0; j < EPL; j++) d[j] = lrD[j] - lrreg * x[q][j];
-                    continue;
+                for (int q = 0; q < RIF; q++) {
+                    const int c = it[q];
+                    if (c < 0) continue;
+                    if (!listed || ballot64(spec == c) != 0) sm |= 1u << q; else common |= 1u << q;
                 }
+                return common | (sm << 16);
+            },
+                [&](int, int c, const T (&x)[EPL], T (&d)[EPL]) {
 #pragma unroll
                 for (int g = 0; g < G; g++) {
-                    const uint64_t hit = __ballot(prevl[g] == c);
+                    const uint64_t hit = ballot64(prevl[g] == c);
                     const bool inprev = hit != 0;
                     T a = 0;
                     if (inprev) a = SIMPLE ? wt0 : __shfl(wt, (int)__ffsll((unsigned long long)hit) - 1, 64);
@@ -330,9 +416,9 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
                     for (int j = 0; j < EPL; j++) d[j] += cpz * vp[g][j] - cnz * vn[g][j];
                 }
 #pragma unroll
-                for (int j = 0; j < EPL; j++) d[j] = lr * (d[j] - reg * x[q][j]);
-              }
-            });
+                for (int j = 0; j < EPL; j++) d[j] = lr * (d[j] - reg * x[j]);
+                return true;
+            }, no_after);
             // Fossil.cpp:249-252
 #pragma unroll
             for (int g = 0; g < G; g++) {
@@ -379,6 +465,19 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
                     pn[g][j] = (valid && k < K) ? P[(int64_t)neg[g] * K + k] : (T)0;
                 }
             }
+            // The rows of each tuple's matched path are requested here, all at once, and used after pass 1: asked for
+            // where they are used they cost one memory round trip each, one after the other.
+            constexpr int LR = 3;   // path rows per tuple held in registers; longer paths fetch the rest in place
+            T px[G][LR][EPL];
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+#pragma unroll
+                for (int r = 0; r < LR; r++) {
+                    const int c = r < np[g] ? uni(__shfl(pathl[g], r, 64)) : 0;
+#pragma unroll
+                    for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; px[g][r][j] = k < K ? P[(int64_t)c * K + k] : (T)0; }
+                }
+            }
             // pass 1.  Tuple g sums the kept rows of positions [0, tpos[g]) except its positive's and its negative's: ONE
             // running sum over the walk, copied for tuple g where the walk passes tpos[g]; the two rows are taken out
             // afterwards (they are in registers already), what each position's id says about each tuple (inside its
@@ -395,36 +494,42 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
             int cp[G], cn[G]; unsigned pos_in = 0, neg_in = 0;
 #pragma unroll
             for (int g = 0; g < G; g++) cp[g] = cn[g] = 0;
-            walk_history<RIF, EPL, false>(P, seq, fo, nullptr, K, lane, tmax, false,
-                [&](int h0, int ids, const int (&)[RIF], const T (&x)[RIF][EPL], T (&)[RIF][EPL], bool (&)[RIF]) {
+            auto no_special = [](int, int, const T (&)[EPL], T (&)[EPL]) { return false; };
+            auto no_after = [](int) {};
+            const T none[EPL] = {}, zero = 0;
+            walk_history<RIF, EPL, false, true>(P, seq, fo, m.hot, K, lane, tmax, false, none, zero,
+                [&](int h0, int ids, const int (&it)[RIF], const T (&x)[RIF][EPL]) {
                 bool edge = false;   // a prefix ends inside this round
 #pragma unroll
                 for (int g = 0; g < G; g++) {
                     const bool in = h0 + lane < tpos[g] && ids >= 0;
-                    cp[g] += __popcll(__ballot(in));
-                    if (__ballot(in && ids == pos[g]) != 0) pos_in |= 1u << g;
-                    if (__ballot(in && ids == neg[g]) != 0) neg_in |= 1u << g;
+                    cp[g] += __popcll(ballot64(in));
+                    if (ballot64(in && ids == pos[g]) != 0) pos_in |= 1u << g;
+                    if (ballot64(in && ids == neg[g]) != 0) neg_in |= 1u << g;
                     edge |= (unsigned)(tpos[g] - h0) < (unsigned)RIF;
                 }
-                if (!edge) {
+                if (edge) {
 #pragma unroll
-                    for (int q = 0; q < RIF; q++)
+                    for (int g = 0; g < G; g++) {
+                        if ((unsigned)(tpos[g] - h0) >= (unsigned)RIF) continue;
 #pragma unroll
-                        for (int j = 0; j < EPL; j++) S[j] += (double)x[q][j];
-                } else {
+                        for (int j = 0; j < EPL; j++) snap[g][j] = S[j];
 #pragma unroll
-                    for (int q = 0; q < RIF; q++) {
+                        for (int q = 0; q < RIF; q++) {
+                            if (it[q] < 0 || h0 + q >= tpos[g]) continue;
 #pragma unroll
-                        for (int g = 0; g < G; g++)
-                            if (tpos[g] == h0 + q) {
-#pragma unroll
-                                for (int j = 0; j < EPL; j++) snap[g][j] = S[j];
-                            }
-#pragma unroll
-                        for (int j = 0; j < EPL; j++) S[j] += (double)x[q][j];
+                            for (int j = 0; j < EPL; j++) snap[g][j] += (double)x[q][j];
+                        }
                     }
                 }
-            });
+#pragma unroll
+                for (int q = 0; q < RIF; q++) {
+                    if (it[q] < 0) continue;
+#pragma unroll
+                    for (int j = 0; j < EPL; j++) S[j] += (double)x[q][j];
+                }
+                return 0u;
+            }, no_special, no_after);
 #pragma unroll
             for (int g = 0; g < G; g++) {
                 if (tpos[g] == tmax) {   // (a prefix that ends where the walk does: the rows past it were read as zeros)
@@ -433,6 +538,8 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
                 }
                 const int kept = cp[g];
                 cp[g] = kept - (int)((pos_in >> g) & 1); cn[g] = kept - (int)((neg_in >> g) & 1);
+#pragma unroll
+                for (int j = 0; j < EPL; j++) if (lane + 64 * j >= K) snap[g][j] = 0;
             }
             T wp[G], wn[G], deri[G];
             T bp[G], bn[G];     // lane 0: the biases as the group found them
@@ -445,7 +552,14 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
                 T sl[EPL];
 #pragma unroll
                 for (int j = 0; j < EPL; j++) sl[j] = 0;
-                for (int r = 0; r < np[g]; r++) {
+#pragma unroll
+                for (int r = 0; r < LR; r++) {
+                    if (r >= np[g]) continue;
+                    const T e = __shfl(etal[g], r, 64);
+#pragma unroll
+                    for (int j = 0; j < EPL; j++) sl[j] += e * px[g][r][j];
+                }
+                for (int r = LR; r < np[g]; r++) {
                     const int c = uni(__shfl(pathl[g], r, 64)); const T e = __shfl(etal[g], r, 64);
 #pragma unroll
                     for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; sl[j] += e * (k < K ? P[(int64_t)c * K + k] : (T)0); }
@@ -494,25 +608,24 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
                 lrreg = lr * lam * (T)nact;
             };
             begin_stretch(0);
-            walk_history<RIF, EPL, true>(P, seq, fo, at_item ? m.hot : nullptr, K, lane, tmax, at_item,
-                [&](int h0, int, const int (&it)[RIF], const T (&x)[RIF][EPL], T (&dd)[RIF][EPL], bool (&upd)[RIF]) {
+            walk_history<RIF, EPL, true, true>(P, seq, fo, m.hot, K, lane, tmax, at_item, lrD, lrreg,
+                [&](int h0, int, const int (&it)[RIF], const T (&)[RIF][EPL]) {
+                unsigned common = 0, sm = 0;
+                const int lim = stretch_end - h0;   // the rows of this round from `lim` on lie past a prefix end: case analysis for them
 #pragma unroll
-              for (int q = 0; q < RIF; q++) {
-                const int c = it[q], h = h0 + q;
-                if (c < 0) continue;
-                T (&d)[EPL] = dd[q];
-                if (h >= stretch_end) begin_stretch(h);
-                if (listed && __ballot(spec == c) == 0) {
-#pragma unroll
-                    for (int j = 0; j < EPL; j++) d[j] = lrD[j] - lrreg * x[q][j];
-                    upd[q] = true;
-                    continue;
+                for (int q = 0; q < RIF; q++) {
+                    const int c = it[q];
+                    if (c < 0) continue;
+                    if (!listed || q >= lim || ballot64(spec == c) != 0) sm |= 1u << q; else common |= 1u << q;
                 }
+                return common | (sm << 16);
+            },
+                [&](int h, int c, const T (&x)[EPL], T (&d)[EPL]) {
                 int nact = 0;
 #pragma unroll
                 for (int g = 0; g < G; g++) {
                     if (h >= tpos[g]) continue;
-                    uint64_t hit = __ballot(pathl[g] == c);
+                    uint64_t hit = ballot64(pathl[g] == c);
                     const bool inpath = hit != 0;
                     T se = 0;
                     while (hit) { se += __shfl(etal[g], (int)__ffsll((unsigned long long)hit) - 1, 64); hit &= hit - 1; }
@@ -528,13 +641,13 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
 #pragma unroll
                     for (int j = 0; j < EPL; j++) d[j] += a * sp[g][j] + b * sn[g][j];
                 }
-                if (nact == 0) continue;
+                if (nact == 0) return false;
                 const T reg = lam * (T)nact;
 #pragma unroll
-                for (int j = 0; j < EPL; j++) d[j] = lr * (d[j] - reg * x[q][j]);
-                upd[q] = true;
-              }
-            });
+                for (int j = 0; j < EPL; j++) d[j] = lr * (d[j] - reg * x[j]);
+                return true;
+            },
+                [&](int h0) { if (stretch_end <= h0 + RIF) begin_stretch(h0 + RIF); });
 #pragma unroll
             for (int g = 0; g < G; g++) {
                 if (g >= ng) continue;
