@@ -322,18 +322,27 @@ def main():
     # target position, averaged over the (user, position) pairs the sampler draws (user uniform, position uniform)
     mean_hist = float(seq_off[-1]) / U
     rebus_rows = None
+    rebus_group_rows = {}
     if args.model == "REBUS":
         lens = np.diff(seq_off)
         elig = np.nonzero(lens >= 2)[0]
         sample_u = elig[:: max(1, len(elig) // 20000)]
         acc = 0.0
+        gacc = {1: 0.0, 2: 0.0, 4: 0.0, 8: 0.0}
         for u in sample_u:
             seq = seq_item[seq_off[u]:seq_off[u + 1]]
             seen, sizes = set(), []
             for x in seq[:-1]:
                 seen.add(int(x)); sizes.append(len(seen))
             acc += float(np.mean(sizes))   # target positions 1 .. n-1: prefix of 1 .. n-1 items
+            # G tuples of one user walk the longest of their G prefixes once: E[|S| of the max of G uniform positions]
+            n = len(sizes)
+            sz = np.asarray(sizes, dtype=np.float64)
+            for G in gacc:
+                p_max = ((np.arange(1, n + 1) / n) ** G) - ((np.arange(0, n) / n) ** G)
+                gacc[G] += float((p_max * sz).sum())
         rebus_rows = acc / len(sample_u)
+        rebus_group_rows = {G: v / len(sample_u) for G, v in gacc.items()}
 
     def measure(e, md, prec_name, steps, warmup, trainer=None, epoch0=0):
         """steps timed SGD epochs on engine e -> the fields of one bench entry."""
@@ -367,8 +376,14 @@ def main():
         grouped = md["group"] == 2 and args.model in GROUP_MODELS
         # algorithmic bytes per triple: every distinct row / scalar a step names, read once + written once.  Steps that
         # share an item by construction (pairs drawing one negative, or one positive and one negative) name it once per pair.
+        # The history models walk a user's history once for a group of G tuples of that user ("user_batch"): the group
+        # names each history row once (REBUS: the rows of the longest of its G prefixes), every tuple its own two items.
+        walk_g = 1
+        if args.model in HISTORY_MODELS:
+            walk_g = max(1, int(e.kernel_stats(6)[0]))
         rows = {"BPRMF": 3, "MC": 3, "HRM_avg": 4, "HRM_max": 4, "TransRec": 4, "TransRec_L1": 4, "FPMC": 6, "PRME": 6,
-                "Fossil": mean_hist + 2, "FossilSimple": mean_hist + 2, "REBUS": (rebus_rows or 0) + 2}[args.model]
+                "Fossil": mean_hist / walk_g + 2, "FossilSimple": mean_hist / walk_g + 2,
+                "REBUS": rebus_group_rows.get(walk_g, rebus_rows or 0) / walk_g + 2}[args.model]
         scalars = {"BPRMF": 2, "TransRec": 2, "TransRec_L1": 2, "Fossil": 2 + 2 * L, "FossilSimple": 4, "REBUS": 2}.get(args.model, 0)
         item_rows_per_role = {"FPMC": 2, "PRME": 2}.get(args.model, 1)
         if args.model in GROUP_MODELS:
@@ -390,6 +405,8 @@ def main():
         roof = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_triple": bytes_per_triple,
                 "tuples_per_launch": int(tuples_per_launch), "avg_launch_ms": round(kern_ms, 4), "launches": int(upd_n),
+                **({"tuples_per_walk": walk_g, "bytes_per_triple_unshared": int(round(2 * ({"REBUS": rebus_rows or 0}.get(args.model, mean_hist) + 2) * K * esz_ + 2 * scalars * esz_))}
+                   if args.model in HISTORY_MODELS else {}),
                 "sampler_ms_per_launch": round(smp_ms / max(smp_n, 1), 4),
                 "partition_ms_per_launch": round(part_ms / launches, 4)}
         # what bounds the scatter: float atomics execute at the memory side at about 1.3 TB/s chip-wide
@@ -413,6 +430,13 @@ def main():
                     ar -= neg_rows * (1.0 - 1.0 / max(md["neg_share"], 2))
                 if md["pos_share"] == 2:
                     ar -= neg_rows * 0.5
+            ab = int(round(ar * K * esz_))
+            rate = ab * tuples_per_launch / (kern_ms * 1e-3) / 1e9
+            roof["atomic"] = {"bytes_per_triple": ab, "achieved": round(rate, 1), "peak": 1300.0, "unit": "GB/s",
+                              "frac": round(rate / 1300.0, 4)}
+        if args.model in HISTORY_MODELS and md["policy"] == 1 and kern_ms > 0:
+            # one atomic row per history row and group, two per tuple for its own items (upper bound: the hottest items are plain stores)
+            ar = (mean_hist if args.model != "REBUS" else rebus_group_rows.get(walk_g, rebus_rows or 0)) / walk_g + 2
             ab = int(round(ar * K * esz_))
             rate = ab * tuples_per_launch / (kern_ms * 1e-3) / 1e9
             roof["atomic"] = {"bytes_per_triple": ab, "achieved": round(rate, 1), "peak": 1300.0, "unit": "GB/s",

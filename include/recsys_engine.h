@@ -280,7 +280,8 @@ int rec_project_rows(rec_engine* e);
  *                   found) only when its user has at least this many training clicks (default 8); the tuples of a user
  *                   with fewer are applied one after the other by the same wavefront, each seeing the one before it
  *   "stale_window"  tuples per update launch for small catalogs (0 = no limit)
- *   "global_window" tuples per update launch for models with a row every tuple touches
+ *   "global_window" tuples per update launch for models with a row every tuple touches (default 2^22 for TransRec; for
+ *                   Fossil / FossilSimple 1/64 of an epoch within 2^18 .. 2^22)
  *   "global_cap"    such a row moves by at most this many steps' worth of learning rate per launch
  *   "eval_screen"   with f32 tables the full-catalog sweep of rec_eval runs on a matrix pipe narrower than fp64 and decides every
  *                   comparison it can prove from a rounding bound; the columns within the bound of a threshold are decided in
@@ -308,7 +309,8 @@ int rec_set_option(rec_engine* e, const char* name, int64_t value);
  * overflowed their lists and were swept again on their own in fp64; *total_ms = the number of columns the screen left to
  * fp64, over all queries.
  * which = 5 (not reset): the last rec_eval_topk - *launches = (user, context) lists produced by the fused sweep,
- * *total_ms = device time of that part (HIP events around its kernels). */
+ * *total_ms = device time of that part (HIP events around its kernels).
+ * which = 6 (not reset, no device call): the launch shape in effect - *total_ms = "user_batch", *launches = "global_window". */
 int rec_kernel_stats(rec_engine* e, int which, double* total_ms, int64_t* launches);
 
 #ifdef __cplusplus

@@ -298,6 +298,19 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     UP(seq_off, seq_off); UP(test_item, test_item); UP(val_item, val_item); UP(clk_off, clk_off);
     UPR(seq_item, seq_off[ub], seq_off[ue] - seq_off[ub], seq_item);
     UPR(first_occ, seq_off[ub], seq_off[ue] - seq_off[ub], first_occ);
+    if (d->model == REC_REBUS) {
+        // the history a REBUS step walks is the first occurrences of a prefix (REBUS.cpp:305-318): those positions alone, packed
+        std::vector<int32_t> kept_pair((size_t)2 * (seq_off[ue] - seq_off[ub]));
+        const int64_t base = seq_off[ub];
+        for (int u = ub; u < ue; u++) {
+            int64_t w = seq_off[u];
+            for (int64_t p = seq_off[u]; p < seq_off[u + 1]; p++)
+                if (first_occ[p]) { kept_pair[2 * (w - base)] = seq_item[p]; kept_pair[2 * (w - base) + 1] = (int32_t)(p - seq_off[u]); w++; }
+            for (; w < seq_off[u + 1]; w++) { kept_pair[2 * (w - base)] = 0; kept_pair[2 * (w - base) + 1] = 0x7fffffff; }
+        }
+        if (!rc) rc = upload_range(e, kept_pair, 0, (int64_t)kept_pair.size(), &m.kept_pair);
+        if (!rc) m.kept_pair -= 2 * base;
+    }
     UPR(clk_item, clk_off[ub], clk_off[ue] - clk_off[ub], clk_item);
     UP(elig, elig); UP(eval_users, eval_users);
     e->train_count_host = train_count;
@@ -377,7 +390,14 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
         e->stale_window = w >= in_flight ? 0 : std::max<int64_t>(16, w);
     }
     // Fossil's global weights move by lr/10 per step with a small curvature: a larger budget than TransRec's r
-    if (d->model == REC_FOSSIL || d->model == REC_FOSSIL_SIMPLE) e->global_cap = 4096;
+    if (d->model == REC_FOSSIL || d->model == REC_FOSSIL_SIMPLE) {
+        e->global_cap = 4096;
+        // A launch is at most 1/64 of an epoch (and 2^18 .. 2^22 tuples): every launch ends on its longest history, so short
+        // launches lose to their tails.  1M users x 200k items x 100M clicks, launches of 2^18 / 2^20 / 2^22 tuples: 0.70 /
+        // 0.61 / 0.59 s per epoch, test AUC after one to four epochs equal within its seed-to-seed spread of 0.002
+        // (scripts/exp_fossil_window.py).
+        while (e->global_window < (1 << 22) && e->global_window * 2 * 64 <= e->steps_per_epoch) e->global_window *= 2;
+    }
     // TransRec's global translation r barely depends on the launch length (200k x 50k corpus: the same AUC trajectory
     // within 0.003 for launches of 2^16 .. 3*10^7 tuples), and longer launches lose less to ramp-up and tails
     if (d->model == REC_TRANSREC || d->model == REC_TRANSREC_L1) e->global_window = 1 << 22;
@@ -394,11 +414,14 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     const double mean_history = U > 0 ? (double)E / (double)U : 0.0;
     e->user_batch = (history_model(d->model) && e->steps_per_epoch >= (1 << 22) && mean_history >= 16.0) ? 2 : 1;
     // Fossil / FossilSimple, whose every step rewrites the user's WHOLE training sequence, walk it once for FOUR tuples where
-    // histories are long (mean >= 32 clicks): 1.32 -> 0.94 s per epoch at 1M users x 200k items x 100M clicks, and on a
-    // 5.9M-step corpus with that catalog the best-validation test AUC is 0.0012 / 0.0009 from the sequential fp64 run (two
-    // tuples per walk: 0.0025 / 0.0017; eight: -0.0003 but no faster).  REBUS, whose tuples of a group end at different
-    // positions of the history, gains nothing beyond two.
-    if ((d->model == REC_FOSSIL || d->model == REC_FOSSIL_SIMPLE) && e->user_batch == 2 && mean_history >= 32.0) e->user_batch = 4;
+    // histories are long (mean >= 32 clicks) and for EIGHT where the mean is >= 64: the float atomics of the walk, one row
+    // per history position and group, are what bounds the kernel.  1M users x 200k items x 100M clicks (mean 98), two /
+    // four / eight tuples per walk: Fossil 1.23 / 0.61 / 0.57 s per epoch, FossilSimple - / 0.63 / 0.45 s; on a 5.9M-step
+    // corpus with that catalog the best-validation test AUC ends 0.0025 / 0.0012 / -0.0003 (Fossil) from the sequential
+    // fp64 run (tests/test_gpu_seq_anchor.py holds the default to 0.005).  REBUS, whose tuples of a group end at different
+    // positions of the history, gains 6 % from four and stays at two.
+    if ((d->model == REC_FOSSIL || d->model == REC_FOSSIL_SIMPLE) && e->user_batch == 2 && mean_history >= 32.0)
+        e->user_batch = mean_history >= 64.0 ? 8 : 4;
     e->dm.pair_min_hist = 8;
     // Owner mode ("owner_neg": launches partitioned by the negative's slice of the catalog, the negatives' deltas summed in
     // LDS by the workgroup that owns the slice) removes half of the float atomics, which bound the update kernel, but it
@@ -1381,7 +1404,12 @@ extern "C" int rec_set_option(rec_engine* e, const char* name, int64_t value)
 
 extern "C" int rec_kernel_stats(rec_engine* e, int which, double* total_ms, int64_t* launches)
 {
-    if (!e || which < 0 || which > 5) { rec_set_error("bad argument"); return -1; }
+    if (!e || which < 0 || which > 6) { rec_set_error("bad argument"); return -1; }
+    if (which == 6) {
+        if (total_ms) *total_ms = (double)e->user_batch;
+        if (launches) *launches = e->global_window;
+        return 0;
+    }
     ENG_HIP(hipSetDevice(e->desc.device));
     ENG_HIP(hipStreamSynchronize(e->st));
     if (which == 4) {

@@ -38,39 +38,46 @@ __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_b
 template <class T> __device__ __forceinline__ T sigm(T x) { return (T)1 / ((T)1 + rexp(x)); }
 template <class T> __device__ __forceinline__ T wsum(T v) { return group_sum<64>(v); }
 
-// Walks the rows tab[seq[h]] for h in [0, hend) (only positions with first[h] set when FIRST), RIF rows per round.
-// round(h0, ids, it, x) is called once per round: lane q < RIF of `ids` holds the item of position h0 + q (-1:
-// position skipped or past the end), it[q] is the same id as a wave-uniform value, x[q] this lane's components of its
-// row (UNDEFINED where it[q] < 0, and on lanes whose component is past K: the caller clears what it sums on those
-// lanes).  With SCATTER set it returns two bit masks over the rows of the round: the rows of the low 16 bits are
+// Walks item rows of one user's history, RIF rows per round: tab[seq[h]] for the positions h in [0, hend), or, when
+// DENSE, the rows of the entries {item, position} of `seq` (pairs, `nent` of them, positions ascending) whose position
+// is below hend - a list that holds only the positions a walk keeps, so that no round is spent on the others.
+// round(h0, ids, hpos, it, x) is called once per round: lane q < RIF of `ids` holds the item of row q of the round (-1:
+// past the end) and of `hpos` its position, it[q] is the same id as a wave-uniform value, x[q] this lane's components
+// of its row (UNDEFINED where it[q] < 0, and on lanes whose component is past K: the caller clears what it sums on
+// those lanes).  With SCATTER set it returns two bit masks over the rows of the round: the rows of the low 16 bits are
 // updated by the common step cD - creg * x (float atomics, or plain stores for hot items / !at_item), the rows of the
-// high 16 bits are handed one by one to special(h, item, row components, delta out), which returns whether to update
-// the row; after(h0) runs when the round's rows have been dealt with (it may change cD / creg for the next round).
+// high 16 bits are handed one by one to special(position, item, row components, delta out), which returns whether to
+// update the row; after() runs when the round's rows have been dealt with (it may change cD / creg for the next round).
 //
 // Memory operations retire in order on a wavefront, a wait is "until at most N are outstanding", and the compiler can
 // only count the operations that are certain to have been issued.  So every load of the loop is unconditional
-// (positions past the end re-read the last one, skipped positions read row 0, lanes past K the last component) and a
-// round is laid out as: request the item ids of the fifth round from here (one load: lane q fetches position h0+q,
-// the ids are read back lane by lane); request the rows (and hot flags: one load, lane q fetches the flag of row q) of
+// (entries past the end re-read the last one, rows past the end read row 0, lanes past K the last component) and a
+// round is laid out as: request the item ids of the fifth round from here (one load: lane q fetches entry h0+q, the
+// ids are read back lane by lane); request the rows (and hot flags: one load, lane q fetches the flag of row q) of
 // the round after the next; compute this round's deltas from registers; issue this round's scatters back to back.
 // The rows a round computes with were requested two rounds earlier, and nothing a scatter needs comes from a load
 // that is younger than the previous round's scatters.
 // A row that round r updates and rounds r+1 / r+2 read again (a repeated item) is read before its update.
-template <int RIF, int EPL, bool SCATTER, bool FIRST, class T, class Round, class Special, class After>
-__device__ __forceinline__ void walk_history(T* tab, const int32_t* seq, const uint8_t* first, const uint8_t* hot, int K, int lane,
+template <int RIF, int EPL, bool SCATTER, bool DENSE, class T, class Round, class Special, class After>
+__device__ __forceinline__ void walk_history(T* tab, const int32_t* seq, int nent, const uint8_t* hot, int K, int lane,
                                              int hend, bool at_item, const T (&cD)[EPL], const T& creg, Round round, Special special, After after)
 {
-    static_assert(RIF <= 16, "one lane per position of a round, two masks of one bit per row");
-    if (hend <= 0) return;
+    static_assert(RIF <= 16, "one lane per row of a round, two masks of one bit per row");
+    if (hend <= 0 || nent <= 0) return;
     uint32_t kc[EPL];
 #pragma unroll
     for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; kc[j] = (uint32_t)(k < K ? k : K - 1); }
     const uint32_t row_bytes = (uint32_t)K * (uint32_t)sizeof(T);
-    auto load_ids = [&](int h0, int& id, int& keep) {
-        int h = h0 + lane; h = h < hend ? h : hend - 1;
-        id = seq[h]; keep = FIRST ? (int)first[h] : 1;
+    const int last = DENSE ? nent - 1 : hend - 1;
+    auto load_ids = [&](int h0, int& id, int& pos) {
+        int h = h0 + lane; h = h < last ? h : last;
+        if (DENSE) { const int2 e = ((const int2*)seq)[h]; id = e.x; pos = e.y; }
+        else { id = seq[h]; pos = 0; }
     };
-    auto resolve = [&](int h0, int id, int keep) { return (lane < RIF && h0 + lane < hend && keep != 0) ? id : -1; };
+    auto resolve = [&](int h0, int id, int pos, int& hpos) {
+        hpos = DENSE ? pos : h0 + lane;
+        return (lane < RIF && h0 + lane <= last && hpos < hend) ? id : -1;
+    };
     auto load_rows = [&](int ids, int& hf, T (&x)[RIF][EPL]) {
         const int idc = ids > 0 ? ids : 0;
         const uint64_t ob = (uint64_t)(uint32_t)idc * row_bytes;   // lane q: byte offset of row q
@@ -88,16 +95,17 @@ __device__ __forceinline__ void walk_history(T* tab, const int32_t* seq, const u
     // register that a load is still going to write has to be moved (a move would wait for the load).  Ids are
     // requested BEFORE the rows requested in the same round: waiting for them three rounds later then waits for no
     // row that was requested after them.
-    int id0, id1, id2 = -1, hot0 = 0, hot1 = 0, hot2 = 0, rid0, keep0, rid1, keep1, rid2, keep2;
+    int id0, id1, id2 = -1, hp0, hp1, hp2 = 0, hot0 = 0, hot1 = 0, hot2 = 0, rid0, rpos0, rid1, rpos1, rid2, rpos2;
     T x0[RIF][EPL], x1[RIF][EPL], x2[RIF][EPL];
-    auto stage = [&](int h0, int idCur, int hotCur, const T (&xCur)[RIF][EPL], int& idLd, int& hotLd, T (&xLd)[RIF][EPL], int& rid, int& keep) {
-        idLd = resolve(h0 + 2 * RIF, rid, keep);
-        load_ids(h0 + 5 * RIF, rid, keep);
+    auto stage = [&](int h0, int idCur, int hpCur, int hotCur, const T (&xCur)[RIF][EPL], int& idLd, int& hpLd, int& hotLd, T (&xLd)[RIF][EPL],
+                     int& rid, int& rpos) {
+        idLd = resolve(h0 + 2 * RIF, rid, rpos, hpLd);
+        load_ids(h0 + 5 * RIF, rid, rpos);
         load_rows(idLd, hotLd, xLd);
         int it[RIF];
 #pragma unroll
         for (int q = 0; q < RIF; q++) it[q] = __builtin_amdgcn_readlane(idCur, q);
-        unsigned masks = round(h0, idCur, it, xCur);
+        unsigned masks = round(h0, idCur, hpCur, it, xCur);
         if constexpr (SCATTER) {
             // (this round's rows are needed from here on whatever the masks say: asking for them once, outside the
             // conditional code below, keeps the compiler from waiting for EVERY outstanding load in front of the loop
@@ -137,25 +145,27 @@ __device__ __forceinline__ void walk_history(T* tab, const int32_t* seq, const u
                     __builtin_memcpy(&xs[j], w, sizeof(T));
                     ds[j] = 0;
                 }
-                if (!special(h0 + q, c, xs, ds)) continue;
+                if (!special(DENSE ? __builtin_amdgcn_readlane(hpCur, q) : h0 + q, c, xs, ds)) continue;
                 T* row = tab + (int64_t)c * K;
                 const bool atc = at_item && !__builtin_amdgcn_readlane(hotCur, q);
 #pragma unroll
                 for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; if (k < K) scat(row + k, ds[j], xs[j], atc); }
             }
-            after(h0);
+            after();
         }
     };
-    load_ids(0, rid0, keep0); load_ids(RIF, rid1, keep1);
-    id0 = resolve(0, rid0, keep0); id1 = resolve(RIF, rid1, keep1);
-    load_ids(2 * RIF, rid2, keep2); load_ids(3 * RIF, rid0, keep0); load_ids(4 * RIF, rid1, keep1);
+    load_ids(0, rid0, rpos0); load_ids(RIF, rid1, rpos1);
+    id0 = resolve(0, rid0, rpos0, hp0); id1 = resolve(RIF, rid1, rpos1, hp1);
+    load_ids(2 * RIF, rid2, rpos2); load_ids(3 * RIF, rid0, rpos0); load_ids(4 * RIF, rid1, rpos1);
     load_rows(id0, hot0, x0); load_rows(id1, hot1, x1);
-    for (int h0 = 0; h0 < hend; h0 += 3 * RIF) {
-        stage(h0, id0, hot0, x0, id2, hot2, x2, rid2, keep2);
-        if (h0 + RIF >= hend) break;
-        stage(h0 + RIF, id1, hot1, x1, id0, hot0, x0, rid0, keep0);
-        if (h0 + 2 * RIF >= hend) break;
-        stage(h0 + 2 * RIF, id2, hot2, x2, id1, hot1, x1, rid1, keep1);
+    // (rows past the end are all at the end: a round whose first row is one holds no other)
+    for (int h0 = 0;; h0 += 3 * RIF) {
+        if (__builtin_amdgcn_readlane(id0, 0) < 0) break;
+        stage(h0, id0, hp0, hot0, x0, id2, hp2, hot2, x2, rid2, rpos2);
+        if (__builtin_amdgcn_readlane(id1, 0) < 0) break;
+        stage(h0 + RIF, id1, hp1, hot1, x1, id0, hp0, hot0, x0, rid0, rpos0);
+        if (__builtin_amdgcn_readlane(id2, 0) < 0) break;
+        stage(h0 + 2 * RIF, id2, hp2, hot2, x2, id1, hp1, hot1, x1, rid1, rpos1);
     }
 }
 
@@ -272,10 +282,10 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
 #pragma unroll
             for (int g = 0; g < G; g++) cp[g] = cn[g] = 0;
             auto no_special = [](int, int, const T (&)[EPL], T (&)[EPL]) { return false; };
-            auto no_after = [](int) {};
+            auto no_after = []() {};
             const T none[EPL] = {}, zero = 0;
-            walk_history<RIF, EPL, false, false>(Ui, seq, nullptr, m.hot, K, lane, nu, false, none, zero,
-                [&](int, int ids, const int (&it)[RIF], const T (&x)[RIF][EPL]) {
+            walk_history<RIF, EPL, false, false>(Ui, seq, nu, m.hot, K, lane, nu, false, none, zero,
+                [&](int, int ids, int, const int (&it)[RIF], const T (&x)[RIF][EPL]) {
 #pragma unroll
                 for (int g = 0; g < G; g++) {
                     cp[g] += __popcll(ballot64(ids == pos[g] && ids >= 0));
@@ -389,8 +399,8 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
                 lrD[j] = lr * D;
             }
             const T lrreg = lr * reg;
-            walk_history<RIF, EPL, true, false>(Ui, seq, nullptr, m.hot, K, lane, nu, at_item, lrD, lrreg,
-                [&](int, int, const int (&it)[RIF], const T (&)[RIF][EPL]) {
+            walk_history<RIF, EPL, true, false>(Ui, seq, nu, m.hot, K, lane, nu, at_item, lrD, lrreg,
+                [&](int, int, int, const int (&it)[RIF], const T (&)[RIF][EPL]) {
                 unsigned common = 0, sm = 0;
 #pragma unroll
                 for (int q = 0; q < RIF; q++) {
@@ -401,8 +411,11 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
                 return common | (sm << 16);
             },
                 [&](int, int c, const T (&x)[EPL], T (&d)[EPL]) {
+                // the common step, corrected for the tuples that list this item (the others' case is the common one)
+                const uint64_t slots = ballot64(spec == c);
 #pragma unroll
                 for (int g = 0; g < G; g++) {
+                    if (listed && (((slots >> (g * (Ls + 2))) & ((1ull << (Ls + 2)) - 1)) == 0)) continue;
                     const uint64_t hit = ballot64(prevl[g] == c);
                     const bool inprev = hit != 0;
                     T a = 0;
@@ -411,12 +424,12 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
                     if (SIMPLE && inprev) { cpz = wp[g] + a; cnz = wn[g] + a; }                       // FossilSimple.cpp:199-203
                     else if (c != pos[g]) { cpz = wp[g] + a; cnz = c != neg[g] ? wn[g] + a : (T)0; }
                     else { cpz = 0; cnz = wn[g] + a; }
-                    cpz *= deri[g]; cnz *= deri[g];
+                    cpz = (cpz - wp[g]) * deri[g]; cnz = (cnz - wn[g]) * deri[g];
 #pragma unroll
                     for (int j = 0; j < EPL; j++) d[j] += cpz * vp[g][j] - cnz * vn[g][j];
                 }
 #pragma unroll
-                for (int j = 0; j < EPL; j++) d[j] = lr * (d[j] - reg * x[j]);
+                for (int j = 0; j < EPL; j++) d[j] = lrD[j] + lr * d[j] - lrreg * x[j];
                 return true;
             }, no_after);
             // Fossil.cpp:249-252
@@ -437,7 +450,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
         } else {
             // ---------------- REBUS, REBUS.cpp:282-444; tuple (u, t-1, neg, -): the history of tuple g is seq[0, tpos[g])
             T* beta = (T*)m.tab[RB_BETA]; T* P = (T*)m.tab[RB_P];
-            const uint8_t* fo = m.first_occ + so;
+            const int32_t* kept = m.kept_pair + 2 * so;   // the positions a REBUS walk keeps (first occurrences), as {item, position}
             int hp[G], hn[G];                               // hot flags of pos / neg, fetched with their rows
             int tpos[G], pos[G], neg[G], np[G], pathl[G];   // pathl / etal: lane r holds the r-th item of tuple g's matched path and its weight
             T etal[G];
@@ -495,32 +508,37 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
 #pragma unroll
             for (int g = 0; g < G; g++) cp[g] = cn[g] = 0;
             auto no_special = [](int, int, const T (&)[EPL], T (&)[EPL]) { return false; };
-            auto no_after = [](int) {};
+            auto no_after = []() {};
             const T none[EPL] = {}, zero = 0;
-            walk_history<RIF, EPL, false, true>(P, seq, fo, m.hot, K, lane, tmax, false, none, zero,
-                [&](int h0, int ids, const int (&it)[RIF], const T (&x)[RIF][EPL]) {
-                bool edge = false;   // a prefix ends inside this round
+            unsigned ended = 0;   // tuples whose prefix has ended: their copy of the sum is taken
+            walk_history<RIF, EPL, false, true>(P, kept, nu, m.hot, K, lane, tmax, false, none, zero,
+                [&](int, int ids, int hpos, const int (&it)[RIF], const T (&x)[RIF][EPL]) {
+                const uint64_t all = ballot64(ids >= 0);
+                unsigned ending = 0, inq[G];
 #pragma unroll
                 for (int g = 0; g < G; g++) {
-                    const bool in = h0 + lane < tpos[g] && ids >= 0;
-                    cp[g] += __popcll(ballot64(in));
+                    const bool in = ids >= 0 && hpos < tpos[g];
+                    const uint64_t ing = ballot64(in);
+                    cp[g] += __popcll(ing);
                     if (ballot64(in && ids == pos[g]) != 0) pos_in |= 1u << g;
                     if (ballot64(in && ids == neg[g]) != 0) neg_in |= 1u << g;
-                    edge |= (unsigned)(tpos[g] - h0) < (unsigned)RIF;
+                    inq[g] = (unsigned)ing;
+                    if (ing != all && !((ended >> g) & 1)) ending |= 1u << g;
                 }
-                if (edge) {
+                if (ending) {   // a prefix ends inside this round (or ended with the round before)
 #pragma unroll
                     for (int g = 0; g < G; g++) {
-                        if ((unsigned)(tpos[g] - h0) >= (unsigned)RIF) continue;
+                        if (!((ending >> g) & 1)) continue;
 #pragma unroll
                         for (int j = 0; j < EPL; j++) snap[g][j] = S[j];
 #pragma unroll
                         for (int q = 0; q < RIF; q++) {
-                            if (it[q] < 0 || h0 + q >= tpos[g]) continue;
+                            if (!((inq[g] >> q) & 1)) continue;
 #pragma unroll
                             for (int j = 0; j < EPL; j++) snap[g][j] += (double)x[q][j];
                         }
                     }
+                    ended |= ending;
                 }
 #pragma unroll
                 for (int q = 0; q < RIF; q++) {
@@ -532,7 +550,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
             }, no_special, no_after);
 #pragma unroll
             for (int g = 0; g < G; g++) {
-                if (tpos[g] == tmax) {   // (a prefix that ends where the walk does: the rows past it were read as zeros)
+                if (!((ended >> g) & 1)) {   // (a prefix that ends where the walk does)
 #pragma unroll
                     for (int j = 0; j < EPL; j++) snap[g][j] = S[j];
                 }
@@ -608,16 +626,19 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
                 lrreg = lr * lam * (T)nact;
             };
             begin_stretch(0);
-            walk_history<RIF, EPL, true, true>(P, seq, fo, m.hot, K, lane, tmax, at_item, lrD, lrreg,
-                [&](int h0, int, const int (&it)[RIF], const T (&)[RIF][EPL]) {
+            int resume_at = -1;   // >= 0: a prefix ended in the round just done, the common step is formed anew for positions from here
+            walk_history<RIF, EPL, true, true>(P, kept, nu, m.hot, K, lane, tmax, at_item, lrD, lrreg,
+                [&](int, int ids, int hpos, const int (&it)[RIF], const T (&)[RIF][EPL]) {
+                const uint64_t valid = ballot64(ids >= 0), inside = ballot64(ids >= 0 && hpos < stretch_end);
                 unsigned common = 0, sm = 0;
-                const int lim = stretch_end - h0;   // the rows of this round from `lim` on lie past a prefix end: case analysis for them
 #pragma unroll
                 for (int q = 0; q < RIF; q++) {
                     const int c = it[q];
                     if (c < 0) continue;
-                    if (!listed || q >= lim || ballot64(spec == c) != 0) sm |= 1u << q; else common |= 1u << q;
+                    // the rows past a prefix end go through the case analysis, like the rows of the tuples' own items
+                    if (!listed || !((inside >> q) & 1) || ballot64(spec == c) != 0) sm |= 1u << q; else common |= 1u << q;
                 }
+                resume_at = inside != valid ? __builtin_amdgcn_readlane(hpos, 63 - __builtin_clzll(valid)) + 1 : -1;
                 return common | (sm << 16);
             },
                 [&](int h, int c, const T (&x)[EPL], T (&d)[EPL]) {
@@ -647,7 +668,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
                 for (int j = 0; j < EPL; j++) d[j] = lr * (d[j] - reg * x[j]);
                 return true;
             },
-                [&](int h0) { if (stretch_end <= h0 + RIF) begin_stretch(h0 + RIF); });
+                [&]() { if (resume_at >= 0) begin_stretch(resume_at); });
 #pragma unroll
             for (int g = 0; g < G; g++) {
                 if (g >= ng) continue;
