@@ -8,11 +8,20 @@
 // pass 1 streams the rows into the history sums, pass 2 re-reads each row (an L2 / Infinity Cache
 // hit) for its own regulariser term and scatters its delta with float atomics.  The rows of the CSR
 // are consecutive in seq_item, so the item ids themselves are read as coalesced runs.
-// The G tuples of a group read the same rows, so the rows are streamed once per group: pass 1
-// accumulates the G pairs of sums side by side, pass 2 scatters the sum of the G deltas (every
-// tuple's regulariser term included) with one atomic per component.  All G tuples see the parameters
-// as they were when the group started, which is what tuples in flight on different wavefronts see of
-// each other anyway.
+// The G tuples of a group read the same rows, so the rows are streamed once per group.  Pass 1 keeps
+// ONE running sum for the group: a tuple's sum is that sum (REBUS: as it stood where the tuple's prefix
+// ended) less the rows of its own positive / negative, which are found by comparing ids, a round of
+// them at a time.  Pass 2 scatters the sum of the G deltas with one atomic per component and row: for
+// a row that is none of the group's positives, negatives or short-term / path items that sum is the
+// same vector for every row (formed once per group; REBUS: once per stretch between two prefix ends)
+// plus the row's own regulariser term - one multiply-add per row; the few other rows go through the
+// per-tuple case analysis of the reference.  All G tuples see the parameters as they were when the
+// group started, which is what tuples in flight on different wavefronts see of each other anyway.
+// What bounds the kernels at 1M users x 200k items x 100M clicks, K = 64, f32 (PMC): REBUS, two
+// tuples per walk, the float atomics (0.92 of the 1.3 TB/s the memory side executes them at); Fossil /
+// FossilSimple, eight per walk, the per-tuple work outside the walks (atomics at 0.5 / 0.6 of that
+// rate).  Float atomics on the few most clicked rows run far below that rate (thousands of adds queue
+// on one address: all-atomics costs REBUS 4x the time per epoch): those rows are plain stores.
 // Parameters that every tuple touches are not scattered per tuple (their atomics would all hit one
 // address): Fossil's global weights WT[0..L) and FossilSimple's alpha collect their gradient sums
 // per block and are folded in by launch_apply_global_history after the launch; they stay constant
@@ -184,8 +193,8 @@ __device__ __forceinline__ int special_items(const int (&shortl)[G], const int (
     return spec;
 }
 
-// (f32, K <= 64, one or two tuples per walk: held to 128 registers, four wavefronts per SIMD - REBUS with two tuples per
-// walk would take 137 and run at three: 102 -> 121 M triples/s on the 1M-user corpus for 7 spilled registers)
+// (f32, K <= 64, one or two tuples per walk: held to 128 registers, four wavefronts per SIMD; more wavefronts did not
+// pay for four tuples per walk: 614 ms per epoch at three or at four per SIMD)
 template <int MODEL, class T, int EPL, int G>
 __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 4 : 1) sgd_history_batch_kernel(DevModel m, const int4* __restrict__ tuples, int64_t n, T lr, int atomic, int CLAIM)
 {
