@@ -124,8 +124,9 @@ template <class T>
 static int upload_range(rec_engine* e, const std::vector<T>& h, int64_t first, int64_t count, const T** dev)
 {
     void* p = nullptr;
-    ENG_HIP(hipMalloc(&p, std::max<size_t>((size_t)count * sizeof(T), 8)));
+    ENG_HIP(hipMalloc(&p, (size_t)count * sizeof(T) + 64));   // (kernels that clamp an index instead of branching may read one element past an empty range)
     e->owned.push_back(p);
+    ENG_HIP(hipMemset(p, 0, (size_t)count * sizeof(T) + 64));
     if (count > 0) ENG_HIP(hipMemcpy(p, h.data() + first, (size_t)count * sizeof(T), hipMemcpyHostToDevice));
     *dev = (const T*)p - first;
     return 0;
@@ -300,16 +301,20 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     UPR(first_occ, seq_off[ub], seq_off[ue] - seq_off[ub], first_occ);
     if (d->model == REC_REBUS) {
         // the history a REBUS step walks is the first occurrences of a prefix (REBUS.cpp:305-318): those positions alone, packed
-        std::vector<int32_t> kept_pair((size_t)2 * (seq_off[ue] - seq_off[ub]));
+        std::vector<int32_t> kept_pair((size_t)2 * (seq_off[ue] - seq_off[ub])), kept_rank((size_t)(seq_off[ue] - seq_off[ub]));
         const int64_t base = seq_off[ub];
         for (int u = ub; u < ue; u++) {
             int64_t w = seq_off[u];
-            for (int64_t p = seq_off[u]; p < seq_off[u + 1]; p++)
+            for (int64_t p = seq_off[u]; p < seq_off[u + 1]; p++) {
+                kept_rank[p - base] = (int32_t)(w - seq_off[u]);
                 if (first_occ[p]) { kept_pair[2 * (w - base)] = seq_item[p]; kept_pair[2 * (w - base) + 1] = (int32_t)(p - seq_off[u]); w++; }
+            }
             for (; w < seq_off[u + 1]; w++) { kept_pair[2 * (w - base)] = 0; kept_pair[2 * (w - base) + 1] = 0x7fffffff; }
         }
         if (!rc) rc = upload_range(e, kept_pair, 0, (int64_t)kept_pair.size(), &m.kept_pair);
         if (!rc) m.kept_pair -= 2 * base;
+        if (!rc) rc = upload_range(e, kept_rank, 0, (int64_t)kept_rank.size(), &m.kept_rank);
+        if (!rc) m.kept_rank -= base;
     }
     UPR(clk_item, clk_off[ub], clk_off[ue] - clk_off[ub], clk_item);
     UP(elig, elig); UP(eval_users, eval_users);

@@ -47,48 +47,60 @@ __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_b
 template <class T> __device__ __forceinline__ T sigm(T x) { return (T)1 / ((T)1 + rexp(x)); }
 template <class T> __device__ __forceinline__ T wsum(T v) { return group_sum<64>(v); }
 
-// Walks item rows of one user's history, RIF rows per round: tab[seq[h]] for the positions h in [0, hend), or, when
-// DENSE, the rows of the entries {item, position} of `seq` (pairs, `nent` of them, positions ascending) whose position
-// is below hend - a list that holds only the positions a walk keeps, so that no round is spent on the others.
-// round(h0, ids, hpos, it, x) is called once per round: lane q < RIF of `ids` holds the item of row q of the round (-1:
-// past the end) and of `hpos` its position, it[q] is the same id as a wave-uniform value, x[q] this lane's components
-// of its row (UNDEFINED where it[q] < 0, and on lanes whose component is past K: the caller clears what it sums on
-// those lanes).  With SCATTER set it returns two bit masks over the rows of the round: the rows of the low 16 bits are
-// updated by the common step cD - creg * x (float atomics, or plain stores for hot items / !at_item), the rows of the
-// high 16 bits are handed one by one to special(position, item, row components, delta out), which returns whether to
-// update the row; after() runs when the round's rows have been dealt with (it may change cD / creg for the next round).
+// Walks item rows of one user's history TWICE (the pass that sums them, then the pass that updates them), RIF rows per
+// round: tab[seq[h]] for the positions h in [0, hend), or, when DENSE, the rows of the first `hend` entries {item,
+// position} of `seq` (pairs, positions ascending) - a list that holds only the positions a walk keeps, so that no
+// round is spent on the others.  Both passes are one stream of rounds: a pass is `R3` rounds (padded to a multiple of
+// three), round t of the stream is round t - R3 of the second pass when t >= R3, and the rows and ids a round needs are
+// requested two and five rounds ahead IN THE STREAM - the last rounds of the first pass request the first rows of the
+// second, so the work between the passes waits for no load of the walk.
+//
+// round(t, ids, hpos, it, x) is called once per round that holds a row: lane q < RIF of `ids` holds the item of row q
+// of the round (-1: past the end) and of `hpos` its position, it[q] is the same id as a wave-uniform value, x[q] this
+// lane's components of its row (UNDEFINED where it[q] < 0, and on lanes whose component is past K: the caller clears
+// what it sums on those lanes).  In the pass that updates (SCATTER) it returns two bit masks over the rows of the
+// round: the rows of the low 16 bits are updated by the common step cD - creg * x (float atomics, or plain stores for
+// hot items / !at_item), the rows of the high 16 bits are handed one by one to special(position, item, row components,
+// delta out), which returns whether to update the row; after() runs when the round's rows have been dealt with (it
+// may change cD / creg for the next round).
 //
 // Memory operations retire in order on a wavefront, a wait is "until at most N are outstanding", and the compiler can
-// only count the operations that are certain to have been issued.  So every load of the loop is unconditional
+// only count the operations that are certain to have been issued.  So every load of the loops is unconditional
 // (entries past the end re-read the last one, rows past the end read row 0, lanes past K the last component) and a
 // round is laid out as: request the item ids of the fifth round from here (one load: lane q fetches entry h0+q, the
 // ids are read back lane by lane); request the rows (and hot flags: one load, lane q fetches the flag of row q) of
 // the round after the next; compute this round's deltas from registers; issue this round's scatters back to back.
 // The rows a round computes with were requested two rounds earlier, and nothing a scatter needs comes from a load
-// that is younger than the previous round's scatters.
+// that is younger than the previous round's scatters.  Round t keeps its rows in buffer t % 3 and its raw ids in slot
+// t % 3; the loops are unrolled three times so that no register that a load is still going to write has to be moved
+// (a move would wait for the load).
 // A row that round r updates and rounds r+1 / r+2 read again (a repeated item) is read before its update.
-template <int RIF, int EPL, bool SCATTER, bool DENSE, class T, class Round, class Special, class After>
-__device__ __forceinline__ void walk_history(T* tab, const int32_t* seq, int nent, const uint8_t* hot, int K, int lane,
-                                             int hend, bool at_item, const T (&cD)[EPL], const T& creg, Round round, Special special, After after)
-{
+template <int RIF, int EPL, bool DENSE, class T>
+struct HistoryWalk {
     static_assert(RIF <= 16, "one lane per row of a round, two masks of one bit per row");
-    if (hend <= 0 || nent <= 0) return;
-    uint32_t kc[EPL];
-#pragma unroll
-    for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; kc[j] = (uint32_t)(k < K ? k : K - 1); }
-    const uint32_t row_bytes = (uint32_t)K * (uint32_t)sizeof(T);
-    const int last = DENSE ? nent - 1 : hend - 1;
-    auto load_ids = [&](int h0, int& id, int& pos) {
-        int h = h0 + lane; h = h < last ? h : last;
-        if (DENSE) { const int2 e = ((const int2*)seq)[h]; id = e.x; pos = e.y; }
-        else { id = seq[h]; pos = 0; }
-    };
-    auto resolve = [&](int h0, int id, int pos, int& hpos) {
-        hpos = DENSE ? pos : h0 + lane;
-        return (lane < RIF && h0 + lane <= last && hpos < hend) ? id : -1;
-    };
-    auto load_rows = [&](int ids, int& hf, T (&x)[RIF][EPL]) {
-        const int idc = ids > 0 ? ids : 0;
+    T* tab; const int32_t* seq; const uint8_t* hot;
+    int K, lane, hend, last, R3;
+    uint32_t kc[EPL], row_bytes;
+    int id[3], hp[3], hotf[3], rid[3], rpos[3];
+    T x[3][RIF][EPL];
+
+    __device__ __forceinline__ void load_ids(int t, int slot)
+    {
+        const int tl = t < R3 ? t : t - R3;          // (rounds past the second pass read its padding again: never used)
+        int h = tl * RIF + lane; h = h < last ? h : last;
+        if (DENSE) { const int2 e = ((const int2*)seq)[h]; rid[slot] = e.x; rpos[slot] = e.y; }
+        else { rid[slot] = seq[h]; rpos[slot] = 0; }
+    }
+    __device__ __forceinline__ void resolve(int t, int slot)
+    {
+        const int tl = t < R3 ? t : t - R3;
+        const int h = tl * RIF + lane;
+        hp[slot] = DENSE ? rpos[slot] : h;
+        id[slot] = (lane < RIF && h < hend && t < 2 * R3) ? rid[slot] : -1;
+    }
+    __device__ __forceinline__ void load_rows(int slot)
+    {
+        const int idc = id[slot] > 0 ? id[slot] : 0;
         const uint64_t ob = (uint64_t)(uint32_t)idc * row_bytes;   // lane q: byte offset of row q
         const int olo = (int)(uint32_t)ob, ohi = (int)(uint32_t)(ob >> 32);
 #pragma unroll
@@ -96,25 +108,39 @@ __device__ __forceinline__ void walk_history(T* tab, const int32_t* seq, int nen
             const uint64_t o = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(ohi, q) << 32) | (uint32_t)__builtin_amdgcn_readlane(olo, q);
             const T* row = (const T*)((const char*)tab + o);
 #pragma unroll
-            for (int j = 0; j < EPL; j++) x[q][j] = row[kc[j]];
+            for (int j = 0; j < EPL; j++) x[slot][q][j] = row[kc[j]];
         }
-        hf = SCATTER ? (int)hot[idc] : 0;
-    };
-    // Round R keeps its rows in buffer R % 3 and its raw ids in slot R % 3; the loop is unrolled three times so that no
-    // register that a load is still going to write has to be moved (a move would wait for the load).  Ids are
-    // requested BEFORE the rows requested in the same round: waiting for them three rounds later then waits for no
-    // row that was requested after them.
-    int id0, id1, id2 = -1, hp0, hp1, hp2 = 0, hot0 = 0, hot1 = 0, hot2 = 0, rid0, rpos0, rid1, rpos1, rid2, rpos2;
-    T x0[RIF][EPL], x1[RIF][EPL], x2[RIF][EPL];
-    auto stage = [&](int h0, int idCur, int hpCur, int hotCur, const T (&xCur)[RIF][EPL], int& idLd, int& hpLd, int& hotLd, T (&xLd)[RIF][EPL],
-                     int& rid, int& rpos) {
-        idLd = resolve(h0 + 2 * RIF, rid, rpos, hpLd);
-        load_ids(h0 + 5 * RIF, rid, rpos);
-        load_rows(idLd, hotLd, xLd);
+        hotf[slot] = (int)hot[idc];
+    }
+    // rows_ = the rows of the walk (positions, or entries of the dense list): requests the ids of the first two rounds
+    __device__ __forceinline__ void begin(T* tab_, const int32_t* seq_, const uint8_t* hot_, int K_, int lane_, int rows_)
+    {
+        tab = tab_; seq = seq_; hot = hot_; K = K_; lane = lane_; hend = rows_; last = rows_ > 0 ? rows_ - 1 : 0;
+        R3 = 3 * ((rows_ + 3 * RIF - 1) / (3 * RIF));
+#pragma unroll
+        for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; kc[j] = (uint32_t)(k < K ? k : K - 1); }
+        row_bytes = (uint32_t)K * (uint32_t)sizeof(T);
+        load_ids(0, 0); load_ids(1, 1);
+    }
+    // requests the rows of the first two rounds (and the ids of the next three)
+    __device__ __forceinline__ void first_rows()
+    {
+        resolve(0, 0); resolve(1, 1);
+        load_ids(2, 2); load_ids(3, 0); load_ids(4, 1);
+        load_rows(0); load_rows(1);
+    }
+    template <int S, bool SCATTER, class Round, class Special, class After>
+    __device__ __forceinline__ void stage(int t, bool at_item, const T (&cD)[EPL], const T& creg, Round& round, Special& special, After& after)
+    {
+        constexpr int LD = (S + 2) % 3;
+        resolve(t + 2, LD);
+        load_ids(t + 5, LD);
+        load_rows(LD);
+        if (__builtin_amdgcn_readlane(id[S], 0) < 0) return;   // a padding round (rows past the end are all at the end)
         int it[RIF];
 #pragma unroll
-        for (int q = 0; q < RIF; q++) it[q] = __builtin_amdgcn_readlane(idCur, q);
-        unsigned masks = round(h0, idCur, hpCur, it, xCur);
+        for (int q = 0; q < RIF; q++) it[q] = __builtin_amdgcn_readlane(id[S], q);
+        unsigned masks = round(t, id[S], hp[S], it, x[S]);
         if constexpr (SCATTER) {
             // (this round's rows are needed from here on whatever the masks say: asking for them once, outside the
             // conditional code below, keeps the compiler from waiting for EVERY outstanding load in front of the loop
@@ -122,19 +148,19 @@ __device__ __forceinline__ void walk_history(T* tab, const int32_t* seq, int nen
 #pragma unroll
             for (int q = 0; q < RIF; q++)
 #pragma unroll
-                for (int j = 0; j < EPL; j++) asm volatile("" :: "v"(xCur[q][j]));
+                for (int j = 0; j < EPL; j++) asm volatile("" :: "v"(x[S][q][j]));
 #pragma unroll
             for (int q = 0; q < RIF; q++) {
                 if (!((masks >> q) & 1)) continue;
                 T* row = tab + (int64_t)it[q] * K;
-                const bool atc = at_item && !__builtin_amdgcn_readlane(hotCur, q);
+                const bool atc = at_item && !__builtin_amdgcn_readlane(hotf[S], q);
 #pragma unroll
-                for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; if (k < K) scat(row + k, cD[j] - creg * xCur[q][j], xCur[q][j], atc); }
+                for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; if (k < K) scat(row + k, cD[j] - creg * x[S][q][j], x[S][q][j], atc); }
             }
             unsigned sm = (unsigned)uni((int)(masks >> 16));
             while (sm) {
                 const int q = __builtin_ctz(sm); sm &= sm - 1;
-                const int c = __builtin_amdgcn_readlane(idCur, q);
+                const int c = __builtin_amdgcn_readlane(id[S], q);
                 T xs[EPL], ds[EPL];
 #pragma unroll
                 for (int j = 0; j < EPL; j++) {
@@ -146,7 +172,7 @@ __device__ __forceinline__ void walk_history(T* tab, const int32_t* seq, int nen
 #pragma unroll
                     for (int qq = 0; qq < RIF; qq++) {
                         uint32_t v[sizeof(T) / 4];
-                        __builtin_memcpy(v, &xCur[qq][j], sizeof(T));
+                        __builtin_memcpy(v, &x[S][qq][j], sizeof(T));
                         const uint32_t msk = q == qq ? ~0u : 0u;
 #pragma unroll
                         for (unsigned i = 0; i < sizeof(T) / 4; i++) w[i] |= v[i] & msk;
@@ -154,29 +180,27 @@ __device__ __forceinline__ void walk_history(T* tab, const int32_t* seq, int nen
                     __builtin_memcpy(&xs[j], w, sizeof(T));
                     ds[j] = 0;
                 }
-                if (!special(DENSE ? __builtin_amdgcn_readlane(hpCur, q) : h0 + q, c, xs, ds)) continue;
+                if (!special(__builtin_amdgcn_readlane(hp[S], q), c, xs, ds)) continue;
                 T* row = tab + (int64_t)c * K;
-                const bool atc = at_item && !__builtin_amdgcn_readlane(hotCur, q);
+                const bool atc = at_item && !__builtin_amdgcn_readlane(hotf[S], q);
 #pragma unroll
                 for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; if (k < K) scat(row + k, ds[j], xs[j], atc); }
             }
             after();
         }
-    };
-    load_ids(0, rid0, rpos0); load_ids(RIF, rid1, rpos1);
-    id0 = resolve(0, rid0, rpos0, hp0); id1 = resolve(RIF, rid1, rpos1, hp1);
-    load_ids(2 * RIF, rid2, rpos2); load_ids(3 * RIF, rid0, rpos0); load_ids(4 * RIF, rid1, rpos1);
-    load_rows(id0, hot0, x0); load_rows(id1, hot1, x1);
-    // (rows past the end are all at the end: a round whose first row is one holds no other)
-    for (int h0 = 0;; h0 += 3 * RIF) {
-        if (__builtin_amdgcn_readlane(id0, 0) < 0) break;
-        stage(h0, id0, hp0, hot0, x0, id2, hp2, hot2, x2, rid2, rpos2);
-        if (__builtin_amdgcn_readlane(id1, 0) < 0) break;
-        stage(h0 + RIF, id1, hp1, hot1, x1, id0, hp0, hot0, x0, rid0, rpos0);
-        if (__builtin_amdgcn_readlane(id2, 0) < 0) break;
-        stage(h0 + 2 * RIF, id2, hp2, hot2, x2, id1, hp1, hot1, x1, rid1, rpos1);
     }
-}
+    // one pass: SCATTER = false the first (rounds 0 .. R3 of the stream), true the second (R3 .. 2 R3)
+    template <bool SCATTER, class Round, class Special, class After>
+    __device__ __forceinline__ void pass(bool at_item, const T (&cD)[EPL], const T& creg, Round round, Special special, After after)
+    {
+        const int t0 = SCATTER ? R3 : 0;
+        for (int t = t0; t < t0 + R3; t += 3) {
+            stage<0, SCATTER>(t, at_item, cD, creg, round, special, after);
+            stage<1, SCATTER>(t + 1, at_item, cD, creg, round, special, after);
+            stage<2, SCATTER>(t + 2, at_item, cD, creg, round, special, after);
+        }
+    }
+};
 
 // The items of a group of G tuples whose rows need more than the common step of pass 2 (the positive, the negative
 // and the up to Ls short-term / path items of every tuple), one per lane: slot g * (Ls + 2) + r.
@@ -244,41 +268,67 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
             T* Ui = (T*)m.tab[SIMPLE ? FS_UI : FO_UI];
             T* V = (T*)m.tab[SIMPLE ? FS_V : FO_V];
             // tuple: Fossil (u, t, neg, -), FossilSimple (u, prev, pos, neg)
-            int pos[G], neg[G], np[G], prevl[G];   // prevl: lane ind holds the ind-th previous item of tuple g
-            int hp[G], hn[G];                      // hot flags of pos / neg, fetched with their rows
-            T vp[G][EPL], vn[G][EPL], sp[G][EPL], sn[G][EPL];
+            HistoryWalk<RIF, EPL, false, T> walk;
+            walk.begin(Ui, seq, m.hot, K, lane, nu);   // (its first loads travel with the tuples' own rows)
+            // Every load of the set-up is unconditional (the slots past the group's end repeat tuple 0, lanes past K read
+            // the last component) and the loads of one dependency level are issued together for all G tuples: a branch,
+            // or a wave-uniform value taken out of a loaded register, between two loads makes the second wait for the
+            // first - set up tuple by tuple, a group of eight waited for memory some seventy times.
+            uint32_t kc[EPL];
+#pragma unroll
+            for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; kc[j] = (uint32_t)(k < K ? k : K - 1); }
+            // (a zero the compiler cannot see through: added to a wave-uniform index it keeps the loaded value in a vector
+            // register until it is asked for, instead of a copy to a scalar register - and the wait that needs - at the load)
+            int vz = 0; asm volatile("" : "+v"(vz));
+            int tpos[G], pos[G], neg[G], np[G], prevl[G], pos_r[G];   // prevl: lane ind holds the ind-th previous item of tuple g
+#pragma unroll
+            for (int g = 0; g < G; g++) {   // level 2: what the tuples and the sequence say
+                tpos[g] = SIMPLE ? 0 : uni(tg[g].y);
+                neg[g] = uni(SIMPLE ? tg[g].w : tg[g].z);
+                np[g] = SIMPLE ? 1 : (tpos[g] < L ? tpos[g] : L);
+                if (SIMPLE) { pos_r[g] = tg[g].z; prevl[g] = tg[g].y; }
+                else { const int back = tpos[g] - 1 - lane; pos_r[g] = seq[tpos[g] + vz]; prevl[g] = seq[back > 0 ? back : 0]; }
+            }
+            // short-term weights: lane ind holds WT[ind] + WTu[u][ind] (Fossil) / lane 0 alpha + alpha_u[u] (FossilSimple)
+            const int wl = lane < (SIMPLE ? 1 : L) ? lane : 0;
+            T wt_g = SIMPLE ? ((T*)m.tab[FS_ALPHA])[0] : ((T*)m.tab[FO_WT])[wl];
+            T wt_u = SIMPLE ? ((T*)m.tab[FS_ALPHA_U])[u] : ((T*)m.tab[FO_WTU])[(int64_t)u * L + wl];
+#pragma unroll
+            for (int g = 0; g < G; g++) { pos[g] = uni(pos_r[g]); prevl[g] = lane < np[g] ? prevl[g] : -2; }
+            // level 3: the rows of the tuples' own items (the positive's and the negative's rows in the history table too:
+            // pass 1 sums every position and takes these out afterwards) and of their short-term items
+            constexpr int LR = 3;   // short-term rows per tuple held in registers; longer contexts fetch the rest in place
+            int hp[G], hn[G];       // hot flags of pos / neg
+            T bp[G], bn[G];         // the biases as the group found them
+            T vp[G][EPL], vn[G][EPL], sp[G][EPL], sn[G][EPL], uip[G][EPL], uin[G][EPL], px[G][LR][EPL];
 #pragma unroll
             for (int g = 0; g < G; g++) {
-                const bool valid = g < ng;
-                const int tpos = SIMPLE ? 0 : uni(tg[g].y);
-                pos[g] = valid ? uni(SIMPLE ? tg[g].z : seq[tpos]) : -1;
-                neg[g] = valid ? uni(SIMPLE ? tg[g].w : tg[g].z) : -1;
-                np[g] = valid ? (SIMPLE ? 1 : (tpos < L ? tpos : L)) : 0;
-                prevl[g] = lane < np[g] ? (SIMPLE ? tg[g].y : seq[tpos - 1 - lane]) : -2;
-                hp[g] = (valid && (at_item || at_bias)) ? m.hot[pos[g]] : 0; hn[g] = (valid && (at_item || at_bias)) ? m.hot[neg[g]] : 0;
+                hp[g] = m.hot[pos[g] + vz]; hn[g] = m.hot[neg[g] + vz];
+                bp[g] = beta[pos[g]]; bn[g] = beta[neg[g]];
 #pragma unroll
                 for (int j = 0; j < EPL; j++) {
-                    const int k = lane + 64 * j; sp[g][j] = sn[g][j] = 0;
-                    vp[g][j] = (valid && k < K) ? V[(int64_t)pos[g] * K + k] : (T)0;
-                    vn[g][j] = (valid && k < K) ? V[(int64_t)neg[g] * K + k] : (T)0;
+                    vp[g][j] = V[(int64_t)pos[g] * K + kc[j]]; vn[g][j] = V[(int64_t)neg[g] * K + kc[j]];
+                    uip[g][j] = Ui[(int64_t)pos[g] * K + kc[j]]; uin[g][j] = Ui[(int64_t)neg[g] * K + kc[j]];
                 }
-            }
-            // The rows the step needs beside the history - those of each tuple's short-term items, and the positive's own
-            // row in the history table - are requested here, all at once, and used after pass 1: asked for where they
-            // are used they cost one memory round trip each, one after the other.
-            constexpr int LR = 3;   // short-term rows per tuple held in registers; longer contexts fetch the rest in place
-            T px[G][LR][EPL], uip[G][EPL];
-#pragma unroll
-            for (int g = 0; g < G; g++) {
-                const int cpos = pos[g] > 0 ? pos[g] : 0;
-#pragma unroll
-                for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; uip[g][j] = k < K ? Ui[(int64_t)cpos * K + k] : (T)0; }
 #pragma unroll
                 for (int ind = 0; ind < LR; ind++) {
-                    const int c = ind < np[g] ? uni(__shfl(prevl[g], ind, 64)) : cpos;
+                    const int cl = uni(__shfl(prevl[g], ind, 64));   // -2 past the tuple's short-term items: row 0 is read then, and not used
+                    const int c = cl > 0 ? cl : 0;
 #pragma unroll
-                    for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; px[g][ind][j] = k < K ? Ui[(int64_t)c * K + k] : (T)0; }
+                    for (int j = 0; j < EPL; j++) px[g][ind][j] = Ui[(int64_t)c * K + kc[j]];
                 }
+            }
+            walk.first_rows();
+            __builtin_amdgcn_sched_barrier(0);   // (the instruction scheduler would move the masking below up between the loads, tuple by tuple)
+            // what the slots past the group's end and the lanes past K must not contribute
+            if (lane >= (SIMPLE ? 1 : L)) wt_g = wt_u = 0;
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                hp[g] = uni(hp[g]); hn[g] = uni(hn[g]);
+                if (g >= ng) { pos[g] = neg[g] = -1; np[g] = 0; prevl[g] = -2; hp[g] = hn[g] = 0; }
+                if (!(at_item || at_bias)) hp[g] = hn[g] = 0;
+#pragma unroll
+                for (int j = 0; j < EPL; j++) { sp[g][j] = sn[g][j] = 0; if (lane + 64 * j >= K) vp[g][j] = vn[g][j] = 0; }
             }
             // pass 1: history sums, Fossil.cpp:140-153.  Every tuple of the group sums the whole sequence except the
             // positions that hold its positive / its negative: ONE sum over all positions (in fp64 whatever the tables'
@@ -293,7 +343,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
             auto no_special = [](int, int, const T (&)[EPL], T (&)[EPL]) { return false; };
             auto no_after = []() {};
             const T none[EPL] = {}, zero = 0;
-            walk_history<RIF, EPL, false, false>(Ui, seq, nu, m.hot, K, lane, nu, false, none, zero,
+            walk.template pass<false>(false, none, zero,
                 [&](int, int ids, int, const int (&it)[RIF], const T (&x)[RIF][EPL]) {
 #pragma unroll
                 for (int g = 0; g < G; g++) {
@@ -317,24 +367,13 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
                 cp[g] = nu - op; cn[g] = nu - on;
 #pragma unroll
                 for (int j = 0; j < EPL; j++) {
-                    const int k = lane + 64 * j;
-                    spd[g][j] = snd[g][j] = S[j];
-                    if (g < ng) spd[g][j] -= (double)op * (double)uip[g][j];
-                    if (g < ng && on > 0 && k < K) snd[g][j] -= (double)on * (double)Ui[(int64_t)neg[g] * K + k];
+                    spd[g][j] = S[j] - (double)op * (double)uip[g][j];
+                    snd[g][j] = S[j] - (double)on * (double)uin[g][j];
                 }
-            }
-            // short-term weights: lane ind holds WT[ind] + WTu[u][ind] (Fossil) / lane 0 alpha + alpha_u[u] (FossilSimple)
-            T wt_g = 0, wt_u = 0;
-            if (lane < (SIMPLE ? 1 : L)) {
-                if (SIMPLE) { wt_g = ((T*)m.tab[FS_ALPHA])[0]; wt_u = ((T*)m.tab[FS_ALPHA_U])[u]; }
-                else { wt_g = ((T*)m.tab[FO_WT])[lane]; wt_u = ((T*)m.tab[FO_WTU])[(int64_t)u * L + lane]; }
             }
             const T wt = wt_g + wt_u;
             T wp[G], wn[G], deri[G];
             T user_delta = 0;   // this lane's WTu[u][lane] / alpha_u[u] delta summed over the group
-            T bp[G], bn[G];     // lane 0: the biases as the group found them
-#pragma unroll
-            for (int g = 0; g < G; g++) { bp[g] = (lane == 0 && g < ng) ? beta[pos[g]] : (T)0; bn[g] = (lane == 0 && g < ng) ? beta[neg[g]] : (T)0; }
 #pragma unroll
             for (int g = 0; g < G; g++) {
                 wp[g] = cp[g] > 0 ? rpow((T)cp[g], (T)-0.2) : (T)0; wn[g] = cn[g] > 0 ? rpow((T)cn[g], (T)-0.2) : (T)0;
@@ -371,19 +410,21 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
                 T s1 = 0, s2 = 0;
 #pragma unroll
                 for (int j = 0; j < EPL; j++) { s1 += sp[g][j] * vp[g][j]; s2 += sn[g][j] * vn[g][j]; }
-                const T bpos = bp[g], bneg = bn[g];
-                const T x_uij = __shfl(bpos - bneg, 0, 64) + (wsum(s1) - wsum(s2));
+                const T x_uij = bp[g] - bn[g] + (wsum(s1) - wsum(s2));
                 deri[g] = sigm(x_uij);
-                if (lane == 0) {
-                    scat(beta + pos[g], lr * (deri[g] - breg * bpos), bpos, at_bias && !hp[g]);
-                    scat(beta + neg[g], lr * (-deri[g] - breg * bneg), bneg, at_bias && !hn[g]);
-                }
                 if (lane < np[g]) {
                     gsum += deri[g] * grad_mine; gcnt += 1;
                     // "- lambda * WT[ind]" in the two aliasing branches, Fossil.cpp:201,205
                     const T regv = (SIMPLE || (prevl[g] != pos[g] && prevl[g] != neg[g])) ? wt_u : wt_g;
                     user_delta += lr * (deri[g] * grad_mine - lam * regv);
                 }
+            }
+            // (no store before every tuple of the group is computed: the wait for a later tuple's loaded values would wait for it)
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                if (g >= ng || lane != 0) continue;
+                scat(beta + pos[g], lr * (deri[g] - breg * bp[g]), bp[g], at_bias && !hp[g]);
+                scat(beta + neg[g], lr * (-deri[g] - breg * bn[g]), bn[g], at_bias && !hn[g]);
             }
             if (lane < (SIMPLE ? 1 : L) && user_delta != (T)0) {
                 T* wu = SIMPLE ? (T*)m.tab[FS_ALPHA_U] + u : (T*)m.tab[FO_WTU] + (int64_t)u * L + lane;
@@ -408,7 +449,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
                 lrD[j] = lr * D;
             }
             const T lrreg = lr * reg;
-            walk_history<RIF, EPL, true, false>(Ui, seq, nu, m.hot, K, lane, nu, at_item, lrD, lrreg,
+            walk.template pass<true>(at_item, lrD, lrreg,
                 [&](int, int, int, const int (&it)[RIF], const T (&)[RIF][EPL]) {
                 unsigned common = 0, sm = 0;
 #pragma unroll
@@ -465,40 +506,72 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
             T etal[G];
             T pp[G][EPL], pn[G][EPL], sp[G][EPL], sn[G][EPL];
             int tmax = 0;
+            // Every load of the set-up is unconditional (the slots past the group's end repeat tuple 0, lanes past K read
+            // the last component) and the loads of one dependency level are issued together for all G tuples: a branch,
+            // or a wave-uniform value taken out of a loaded register, between two loads makes the second wait for the first.
+            uint32_t kc[EPL];
+#pragma unroll
+            for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; kc[j] = (uint32_t)(k < K ? k : K - 1); }
+            // (a zero the compiler cannot see through: added to a wave-uniform index it keeps the loaded value in a vector
+            // register until it is asked for, instead of a copy to a scalar register - and the wait that needs - at the load)
+            int vz = 0; asm volatile("" : "+v"(vz));
+            const int32_t* rank = m.kept_rank + so;
+            int pos_r[G], kept_r[G]; int64_t po_r[G], pe_r[G];
+#pragma unroll
+            for (int g = 0; g < G; g++) {   // level 2: what the tuples and the sequence say
+                tpos[g] = uni(tg[g].y) + 1;
+                neg[g] = uni(tg[g].z);
+                tmax = tpos[g] > tmax ? tpos[g] : tmax;
+                const int64_t ctx = so + 2 * (int64_t)u + (tpos[g] - 1);
+                pos_r[g] = seq[tpos[g] + vz]; kept_r[g] = rank[tpos[g] + vz]; po_r[g] = m.path_off[ctx + vz]; pe_r[g] = m.path_off[ctx + 1 + vz];
+            }
+            const int nkept = uni(rank[tmax + vz]);   // the rows of the walk: first occurrences among the positions [0, tmax)
+            HistoryWalk<RIF, EPL, true, T> walk;
+            walk.begin(P, kept, m.hot, K, lane, nkept);   // (its first loads travel with the tuples' own rows)
+            // level 3: the tuples' own rows, their matched paths, the Root row (REBUS.cpp:414-418: it stands for an empty path)
+            int cp[G], cn[G];
+            T bp[G], bn[G], proot[EPL];     // bp / bn: the biases as the group found them
+#pragma unroll
+            for (int j = 0; j < EPL; j++) proot[j] = P[(int64_t)I * K + kc[j]];
 #pragma unroll
             for (int g = 0; g < G; g++) {
-                const bool valid = g < ng;
-                tpos[g] = valid ? uni(tg[g].y) + 1 : 0;
-                pos[g] = valid ? uni(seq[tpos[g]]) : -1;
-                neg[g] = valid ? uni(tg[g].z) : -1;
-                np[g] = 0; pathl[g] = -2; etal[g] = 0;
-                if (valid) {
-                    const int64_t ctx = so + 2 * (int64_t)u + (tpos[g] - 1);
-                    const int64_t po = uni(m.path_off[ctx]);
-                    np[g] = uni((int)(m.path_off[ctx + 1] - po));
-                    if (lane < np[g]) { pathl[g] = m.path_item[po + lane]; etal[g] = (T)m.eta[(int64_t)np[g] * L + lane]; }
-                }
-                hp[g] = (valid && (at_item || at_bias)) ? m.hot[pos[g]] : 0; hn[g] = (valid && (at_item || at_bias)) ? m.hot[neg[g]] : 0;
-                tmax = tpos[g] > tmax ? tpos[g] : tmax;
+                pos[g] = uni(pos_r[g]);
+                cp[g] = cn[g] = uni(kept_r[g]);
+                const int64_t po = uni(po_r[g]);
+                np[g] = uni((int)(pe_r[g] - po));
+                pathl[g] = m.path_item[po + (lane < np[g] ? lane : 0)];
+                etal[g] = (T)m.eta[(int64_t)np[g] * L + (lane < L ? lane : 0)];
+                hp[g] = m.hot[pos[g] + vz]; hn[g] = m.hot[neg[g] + vz];
+                bp[g] = beta[pos[g]]; bn[g] = beta[neg[g]];
 #pragma unroll
-                for (int j = 0; j < EPL; j++) {
-                    const int k = lane + 64 * j;
-                    pp[g][j] = (valid && k < K) ? P[(int64_t)pos[g] * K + k] : (T)0;
-                    pn[g][j] = (valid && k < K) ? P[(int64_t)neg[g] * K + k] : (T)0;
-                }
+                for (int j = 0; j < EPL; j++) { pp[g][j] = P[(int64_t)pos[g] * K + kc[j]]; pn[g][j] = P[(int64_t)neg[g] * K + kc[j]]; }
             }
-            // The rows of each tuple's matched path are requested here, all at once, and used after pass 1: asked for
-            // where they are used they cost one memory round trip each, one after the other.
+            walk.first_rows();
+            __builtin_amdgcn_sched_barrier(0);   // (the instruction scheduler would move what follows up between the loads, tuple by tuple)
+            // level 4: the rows of the matched paths (used after pass 1)
             constexpr int LR = 3;   // path rows per tuple held in registers; longer paths fetch the rest in place
             T px[G][LR][EPL];
 #pragma unroll
             for (int g = 0; g < G; g++) {
+                pathl[g] = lane < np[g] ? pathl[g] : -2; etal[g] = lane < np[g] ? etal[g] : (T)0;
 #pragma unroll
                 for (int r = 0; r < LR; r++) {
-                    const int c = r < np[g] ? uni(__shfl(pathl[g], r, 64)) : 0;
+                    const int cl = uni(__shfl(pathl[g], r, 64));   // -2 past the path's end: row 0 is read then, and not used
+                    const int c = cl > 0 ? cl : 0;
 #pragma unroll
-                    for (int j = 0; j < EPL; j++) { const int k = lane + 64 * j; px[g][r][j] = k < K ? P[(int64_t)c * K + k] : (T)0; }
+                    for (int j = 0; j < EPL; j++) px[g][r][j] = P[(int64_t)c * K + kc[j]];
                 }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // what the slots past the group's end and the lanes past K must not contribute
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                hp[g] = uni(hp[g]); hn[g] = uni(hn[g]);
+                if (g >= ng) { tpos[g] = 0; pos[g] = neg[g] = -1; np[g] = 0; cp[g] = cn[g] = 0; pathl[g] = -2; etal[g] = 0; hp[g] = hn[g] = 0; }
+                if (!(at_item || at_bias)) hp[g] = hn[g] = 0;
+#pragma unroll
+                for (int j = 0; j < EPL; j++)
+                    if (lane + 64 * j >= K) { pp[g][j] = pn[g][j] = 0; for (int r = 0; r < LR; r++) px[g][r][j] = 0; }
             }
             // pass 1.  Tuple g sums the kept rows of positions [0, tpos[g]) except its positive's and its negative's: ONE
             // running sum over the walk, copied for tuple g where the walk passes tpos[g]; the two rows are taken out
@@ -513,14 +586,12 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
 #pragma unroll
                 for (int g = 0; g < G; g++) snap[g][j] = 0;
             }
-            int cp[G], cn[G]; unsigned pos_in = 0, neg_in = 0;
-#pragma unroll
-            for (int g = 0; g < G; g++) cp[g] = cn[g] = 0;
+            unsigned pos_in = 0, neg_in = 0;
             auto no_special = [](int, int, const T (&)[EPL], T (&)[EPL]) { return false; };
             auto no_after = []() {};
             const T none[EPL] = {}, zero = 0;
             unsigned ended = 0;   // tuples whose prefix has ended: their copy of the sum is taken
-            walk_history<RIF, EPL, false, true>(P, kept, nu, m.hot, K, lane, tmax, false, none, zero,
+            walk.template pass<false>(false, none, zero,
                 [&](int, int ids, int hpos, const int (&it)[RIF], const T (&x)[RIF][EPL]) {
                 const uint64_t all = ballot64(ids >= 0);
                 unsigned ending = 0, inq[G];
@@ -528,7 +599,6 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
                 for (int g = 0; g < G; g++) {
                     const bool in = ids >= 0 && hpos < tpos[g];
                     const uint64_t ing = ballot64(in);
-                    cp[g] += __popcll(ing);
                     if (ballot64(in && ids == pos[g]) != 0) pos_in |= 1u << g;
                     if (ballot64(in && ids == neg[g]) != 0) neg_in |= 1u << g;
                     inq[g] = (unsigned)ing;
@@ -563,15 +633,11 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
 #pragma unroll
                     for (int j = 0; j < EPL; j++) snap[g][j] = S[j];
                 }
-                const int kept = cp[g];
-                cp[g] = kept - (int)((pos_in >> g) & 1); cn[g] = kept - (int)((neg_in >> g) & 1);
+                cp[g] -= (int)((pos_in >> g) & 1); cn[g] -= (int)((neg_in >> g) & 1);
 #pragma unroll
                 for (int j = 0; j < EPL; j++) if (lane + 64 * j >= K) snap[g][j] = 0;
             }
             T wp[G], wn[G], deri[G];
-            T bp[G], bn[G];     // lane 0: the biases as the group found them
-#pragma unroll
-            for (int g = 0; g < G; g++) { bp[g] = (lane == 0 && g < ng) ? beta[pos[g]] : (T)0; bn[g] = (lane == 0 && g < ng) ? beta[neg[g]] : (T)0; }
 #pragma unroll
             for (int g = 0; g < G; g++) {
                 wp[g] = cp[g] > 0 ? rpow((T)cp[g], (T)m.alpha) : (T)0; wn[g] = cn[g] > 0 ? rpow((T)cn[g], (T)m.alpha) : (T)0;
@@ -603,13 +669,15 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
                     sp[g][j] = (T)dp; sn[g][j] = (T)dn;
                     qd += dn * dn - dp * dp;
                 }
-                const T bpos = bp[g], bneg = bn[g];
-                const T x_uij = __shfl(-bpos + bneg, 0, 64) + (T)group_sum<64>(qd);
+                const T x_uij = bn[g] - bp[g] + (T)group_sum<64>(qd);
                 deri[g] = sigm(x_uij);
-                if (lane == 0) {
-                    scat(beta + pos[g], lr * (-deri[g] - breg * bpos), bpos, at_bias && !hp[g]);   // [9]
-                    scat(beta + neg[g], lr * (deri[g] - breg * bneg), bneg, at_bias && !hn[g]);    // [10]
-                }
+            }
+            // (no store before every tuple of the group is computed: the wait for a later tuple's loaded values would wait for it)
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                if (g >= ng || lane != 0) continue;
+                scat(beta + pos[g], lr * (-deri[g] - breg * bp[g]), bp[g], at_bias && !hp[g]);   // [9]
+                scat(beta + neg[g], lr * (deri[g] - breg * bn[g]), bn[g], at_bias && !hn[g]);    // [10]
             }
             // pass 2.  A kept row of position h that is none of the group's positives, negatives or path items receives
             // deri * (wn * dist_neg - wp * dist_pos) from every tuple whose prefix holds h, and its own regulariser term
@@ -636,7 +704,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
             };
             begin_stretch(0);
             int resume_at = -1;   // >= 0: a prefix ended in the round just done, the common step is formed anew for positions from here
-            walk_history<RIF, EPL, true, true>(P, kept, nu, m.hot, K, lane, tmax, at_item, lrD, lrreg,
+            walk.template pass<true>(at_item, lrD, lrreg,
                 [&](int, int ids, int hpos, const int (&it)[RIF], const T (&)[RIF][EPL]) {
                 const uint64_t valid = ballot64(ids >= 0), inside = ballot64(ids >= 0 && hpos < stretch_end);
                 unsigned common = 0, sm = 0;
@@ -688,7 +756,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
                 for (int j = 0; j < EPL; j++) {
                     const int k = lane + 64 * j;
                     if (k >= K) continue;
-                    if (root) { const T pr = P[(int64_t)I * K + k]; scat(P + (int64_t)I * K + k, lr * (deri[g] * (-sp[g][j] + sn[g][j]) - lam * pr), pr, at_item); }   // [3]
+                    if (root) scat(P + (int64_t)I * K + k, lr * (deri[g] * (-sp[g][j] + sn[g][j]) - lam * proot[j]), proot[j], at_item);   // [3]
                     if (!nin) scat(P + (int64_t)neg[g] * K + k, lr * (deri[g] * (-sn[g][j]) - lam * pn[g][j]), pn[g][j], an);       // [8]
                     if (!pin) scat(P + (int64_t)pos[g] * K + k, lr * (deri[g] * (sp[g][j]) - lam * pp[g][j]), pp[g][j], ap);        // [6]
                 }

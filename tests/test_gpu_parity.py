@@ -937,3 +937,49 @@ def test_user_shards_partition_sampling_and_evaluation(model):
     assert got[7] == want[7] and np.allclose(got, want, rtol=1e-12, atol=1e-12)
     full.close()
 
+
+
+@pytest.mark.parametrize("model", ["FossilSimple", "Fossil", "REBUS"])
+def test_history_kernels_on_long_histories_match_updateFactors(model):
+    """The toy users above have a handful of clicks: one round of the history walk.  Here 2000 users x 1500 items x 200k
+    clicks (mean history 100, up to 400: many rounds, both passes streaming, the packed list of first occurrences for REBUS):
+    64 single tuples through the Hogwild kernel against updateFactors (REBUS: the same arithmetic, 1e-9; Fossil /
+    FossilSimple: a repeated item of the history is read before its first update, an O(lr^2) difference, 1e-5), then groups
+    of 2 and 8 tuples of one user against the sum of their single steps from the same parameters (users with fewer than 8
+    clicks, whose groups are applied one after the other, left out)."""
+    import torch
+    from bench import make_synthetic
+    U, I, K, L = 2000, 1500, 64, 3
+    seq_off, seq_item, test, val, _ = make_synthetic(U, I, 200_000, 7, torch.device("cuda:0"))
+    po = pi = None
+    kw = dict(L=L, lam=0.01, bias_reg=0.01, relation_reg=0.01, alpha=-0.6 if model == "REBUS" else 0.5)
+    if model == "REBUS":
+        lo, li = ra.fsub_mine(I, seq_off, seq_item, L, 2)
+        po, pi = ra.build_rebus_paths(I, seq_off, seq_item, val, lo, li)
+    e = ra.Engine(model, I, seq_off, seq_item, test, val, K=K, precision=F64, path_off=po, path_item=pi, **kw)
+    o = orc.Oracle(model, U, I, K, seq_off, seq_item, test, val, path_off=po, path_item=pi, **kw)
+    e.set_option("update_policy", 0)
+    e.init_params(3)
+    W0 = e.download()
+    single = 1e-9 if model == "REBUS" else 1e-5
+    for G in (1, 2, 8):
+        e.set_option("user_batch", G)
+        T = e.sample_tuples(64 * G, seed=5, epoch=1)
+        n = 0
+        longest = 0
+        for k in range(0, 64 * G, G):
+            grp = T[k:k + G]
+            nu = int(seq_off[grp[0, 0] + 1] - seq_off[grp[0, 0]])
+            if G > 1 and nu < 8:
+                continue
+            ref = W0.copy()
+            for t in grp:
+                ref += o.replay(W0, t[None, :], 0.05) - W0
+            e.upload(W0)
+            e.sgd_replay(0.05, grp, HOGWILD)
+            err = rel_err(e.download(), ref, floor=1e-1)
+            assert err < single * G, (model, G, grp.tolist(), nu, err)
+            n += 1
+            longest = max(longest, nu)
+        assert n >= 40 and longest >= 100, (model, G, n, longest)
+    e.close()

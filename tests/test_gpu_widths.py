@@ -259,5 +259,7 @@ def test_epoch_that_draws_its_own_tuples_applies_the_samplers_tuples(model, K):
         if model != "HRM_max":
             assert ((outs[other] != W32) != touched).mean() < 0.02, (model, K, other)     # (a sum of steps can round back to the old value)
         far = np.abs(outs["fused"] - outs[other])[touched] > 0.05 * moved
-        assert far.mean() < 0.1, (model, K, other, far.mean())
+        # (TransRec_L1 steps by the SIGN of a difference, TransRec_L1.cpp:207-244: on a row two tuples share, a component near
+        # zero flips with the race and moves by a whole step; measured up to 0.12 of the touched components at K = 256)
+        assert far.mean() < (0.25 if model == "TransRec_L1" else 0.1), (model, K, other, far.mean())
     assert ((outs["other_seed"] != W32) != touched).mean() > 0.05
