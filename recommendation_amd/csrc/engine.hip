@@ -418,15 +418,16 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     // one after the other.
     const double mean_history = U > 0 ? (double)E / (double)U : 0.0;
     e->user_batch = (history_model(d->model) && e->steps_per_epoch >= (1 << 22) && mean_history >= 16.0) ? 2 : 1;
-    // Fossil / FossilSimple, whose every step rewrites the user's WHOLE training sequence, walk it once for FOUR tuples where
-    // histories are long (mean >= 32 clicks) and for EIGHT where the mean is >= 64: the float atomics of the walk, one row
-    // per history position and group, are what bounds the kernel.  1M users x 200k items x 100M clicks (mean 98), two /
-    // four / eight tuples per walk: Fossil 1.23 / 0.61 / 0.57 s per epoch, FossilSimple - / 0.63 / 0.45 s; on a 5.9M-step
-    // corpus with that catalog the best-validation test AUC ends 0.0025 / 0.0012 / -0.0003 (Fossil) from the sequential
-    // fp64 run (tests/test_gpu_seq_anchor.py holds the default to 0.005).  REBUS, whose tuples of a group end at different
-    // positions of the history, gains 6 % from four and stays at two.
-    if ((d->model == REC_FOSSIL || d->model == REC_FOSSIL_SIMPLE) && e->user_batch == 2 && mean_history >= 32.0)
-        e->user_batch = mean_history >= 64.0 ? 8 : 4;
+    // Where histories are long, more tuples share a walk: the float atomics of the walk, one row per history row and GROUP,
+    // are what bounds the kernels.  Fossil / FossilSimple (every step rewrites the user's whole training sequence): four
+    // tuples where the mean history is >= 32 clicks, eight where it is >= 64; REBUS (the tuples of a group end at different
+    // positions, the walk is the longest prefix): four from a mean of 32.  1M users x 200k items x 100M clicks (mean 98),
+    // ms per epoch for two / four / eight tuples per walk: Fossil 1230 / 612 / 438, FossilSimple - / 633 / 364, REBUS 713 /
+    // 565 / 531.  On a 5.9M-step corpus with that catalog the best-validation test AUC ends, against the sequential fp64
+    // run: Fossil +0.0025 / +0.0017 / +0.0007, FossilSimple +0.0014 / +0.0009 / -0.0005, REBUS +0.0005 / +0.0008 / +0.0014
+    // (HIT@50 -0.0009 / -0.0004 / -0.006); tests/test_gpu_seq_anchor.py holds the default to 0.005.
+    if (e->user_batch == 2 && mean_history >= 32.0)
+        e->user_batch = (d->model != REC_REBUS && mean_history >= 64.0) ? 8 : 4;
     e->dm.pair_min_hist = 8;
     // Owner mode ("owner_neg": launches partitioned by the negative's slice of the catalog, the negatives' deltas summed in
     // LDS by the workgroup that owns the slice) removes half of the float atomics, which bound the update kernel, but it
