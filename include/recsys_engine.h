@@ -273,7 +273,7 @@ int rec_project_rows(rec_engine* e);
  *                   of the default, test AUC 0.0007 and HIT@50 2 % (relative) lower at convergence
  *   "user_batch"    Fossil / FossilSimple / REBUS: 1, 2, 4 or 8 consecutive steps of an epoch share their user draw and one
  *                   wavefront walks that user's history once for all of them (default when an epoch is >= 4M steps: 2 where the
- *                   mean training sequence has >= 16 clicks, 4 for Fossil / FossilSimple where it has >= 32; else 1: with very
+ *                   mean training sequence has >= 16 clicks, 4 where it has >= 32, 8 for Fossil / FossilSimple where it has >= 64; else 1: with very
  *                   short histories the tuples of a group mostly coincide and the summed step can diverge);
  *                   (rec_sgd_replay in Hogwild mode uses it when its tuples come grouped the same way)
  *   "pair_min_history"  a group of "user_batch" tuples shares one walk (all of them stepping from the parameters the group

@@ -8,10 +8,9 @@ restatement of updateFactors (oracle/, pinned to the reference by tests/golden) 
 tuples the engine's sampler drew - the reference's sequential semantics at a size its own binary needs hours for - scored
 twice per epoch over six epochs by the engine's evaluation, three seeds per model.  The engine's default update runs the
 same schedule with four seeds.  Compared at the best-validation checkpoint, means over seeds, two-sided: validation and
-test AUC within 0.005, HIT@50 within 0.01.  Measured (engine - sequential, test AUC): Fossil +0.0012, FossilSimple
-+0.0004 (eight tuples per walk, the default at this history length; +0.0017 .. 0.0026 / +0.0009 with four, +0.0027 /
-+0.0014 with two), REBUS +0.0001 (two per walk; REBUS follows the sequential run to 0.002 at every one of the twelve
-checkpoints).
+test AUC within 0.005, HIT@50 within 0.01.  Measured (engine - sequential, test AUC): Fossil +0.0002 .. +0.0012, FossilSimple
+-0.0005 .. +0.0004 (eight tuples per walk, the default at this history length; +0.0017 .. 0.0026 / +0.0009 with four,
++0.0027 / +0.0014 with two), REBUS +0.0008 (four per walk; +0.0005 with two, +0.0014 and HIT@50 -0.006 with eight).
 
 The same comparison on a 20k-item catalog - ten times as many of the ~13 000 tuples in flight per row - has the defaults
 end further above the sequential run (Fossil +0.004, FossilSimple +0.004, REBUS +0.005 with the chip to itself, +0.0005
