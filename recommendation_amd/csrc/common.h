@@ -23,6 +23,7 @@ struct DevModel {
     const int64_t* clk_off;             // [U+1] sorted distinct training items per user
     const int32_t* clk_item;
     const uint8_t* first_occ;           // [E] 1 where a sequence position is the first occurrence of its item
+    const double* len_pow;              // history models: [longest sequence + 2] c^alpha (REBUS) / c^-0.2 (Fossil, FossilSimple), 0 at c = 0
     const int32_t* kept_rank;           // REBUS: [E] first occurrences among the positions of the user's sequence before this one
     const int32_t* kept_pair;           // REBUS: [E][2] per user the {item, position in the sequence} of those positions in order, then {0, INT_MAX}
     const int64_t* path_off;            // REBUS matched paths per context

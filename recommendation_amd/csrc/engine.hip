@@ -299,6 +299,15 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     UP(seq_off, seq_off); UP(test_item, test_item); UP(val_item, val_item); UP(clk_off, clk_off);
     UPR(seq_item, seq_off[ub], seq_off[ue] - seq_off[ub], seq_item);
     UPR(first_occ, seq_off[ub], seq_off[ue] - seq_off[ub], first_occ);
+    if (history_model(d->model)) {
+        // the weight of a history of c rows, |S|^alpha (REBUS.cpp:320-321) / |S|^-0.2 (Fossil.cpp:155-156), for every length there is
+        int64_t longest = 0;
+        for (int u = 0; u < U; u++) longest = std::max(longest, seq_off[u + 1] - seq_off[u]);
+        std::vector<double> len_pow((size_t)longest + 2, 0.0);
+        const double ex = d->model == REC_REBUS ? d->alpha : -0.2;
+        for (size_t c = 1; c < len_pow.size(); c++) len_pow[c] = pow((double)c, ex);
+        UP(len_pow, len_pow);
+    }
     if (d->model == REC_REBUS) {
         // the history a REBUS step walks is the first occurrences of a prefix (REBUS.cpp:305-318): those positions alone, packed
         std::vector<int32_t> kept_pair((size_t)2 * (seq_off[ue] - seq_off[ub])), kept_rank((size_t)(seq_off[ue] - seq_off[ub]));

@@ -202,6 +202,13 @@ struct HistoryWalk {
     }
 };
 
+// lane l of `v` as a wave-uniform double
+__device__ __forceinline__ double lane_double(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
 // The items of a group of G tuples whose rows need more than the common step of pass 2 (the positive, the negative
 // and the up to Ls short-term / path items of every tuple), one per lane: slot g * (Ls + 2) + r.
 template <int G>
@@ -318,6 +325,9 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
                     for (int j = 0; j < EPL; j++) px[g][ind][j] = Ui[(int64_t)c * K + kc[j]];
                 }
             }
+            // (the weight of a sum of c rows, c^-0.2, from the table of all lengths: lane l fetches the entry of nu - l - the sums
+            // leave out the occurrences of the positive / the negative, a few positions at most)
+            const double lenw = m.len_pow[nu - lane > 0 ? nu - lane : 0];
             walk.first_rows();
             __builtin_amdgcn_sched_barrier(0);   // (the instruction scheduler would move the masking below up between the loads, tuple by tuple)
             // what the slots past the group's end and the lanes past K must not contribute
@@ -376,7 +386,8 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
             T user_delta = 0;   // this lane's WTu[u][lane] / alpha_u[u] delta summed over the group
 #pragma unroll
             for (int g = 0; g < G; g++) {
-                wp[g] = cp[g] > 0 ? rpow((T)cp[g], (T)-0.2) : (T)0; wn[g] = cn[g] > 0 ? rpow((T)cn[g], (T)-0.2) : (T)0;
+                wp[g] = (T)(nu - cp[g] < 64 ? lane_double(lenw, nu - cp[g]) : m.len_pow[cp[g]]);
+                wn[g] = (T)(nu - cn[g] < 64 ? lane_double(lenw, nu - cn[g]) : m.len_pow[cn[g]]);
                 if (g >= ng) { wp[g] = wn[g] = 0; deri[g] = 0; continue; }
 #pragma unroll
                 for (int j = 0; j < EPL; j++) { sp[g][j] = (T)((double)wp[g] * spd[g][j]); sn[g][j] = (T)((double)wn[g] * snd[g][j]); }
@@ -548,7 +559,13 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
             }
             walk.first_rows();
             __builtin_amdgcn_sched_barrier(0);   // (the instruction scheduler would move what follows up between the loads, tuple by tuple)
-            // level 4: the rows of the matched paths (used after pass 1)
+            // level 4: the rows of the matched paths (used after pass 1), and the weight of a sum of c rows, c^alpha, from the
+            // table of all lengths: lane 2g + i fetches the entry of (rows of tuple g's prefix) - i, i = 1 in case the positive /
+            // the negative turns out to be one of them
+            int kl = 0;
+#pragma unroll
+            for (int g = 0; g < G; g++) kl = (lane >> 1) == g ? cp[g] : kl;
+            const double lenw = m.len_pow[kl - (lane & 1) > 0 ? kl - (lane & 1) : 0];
             constexpr int LR = 3;   // path rows per tuple held in registers; longer paths fetch the rest in place
             T px[G][LR][EPL];
 #pragma unroll
@@ -640,8 +657,9 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
             T wp[G], wn[G], deri[G];
 #pragma unroll
             for (int g = 0; g < G; g++) {
-                wp[g] = cp[g] > 0 ? rpow((T)cp[g], (T)m.alpha) : (T)0; wn[g] = cn[g] > 0 ? rpow((T)cn[g], (T)m.alpha) : (T)0;
-                if (g >= ng) { deri[g] = 0; continue; }
+                const double wpd = lane_double(lenw, 2 * g + (int)((pos_in >> g) & 1)), wnd = lane_double(lenw, 2 * g + (int)((neg_in >> g) & 1));
+                wp[g] = (T)wpd; wn[g] = (T)wnd;
+                if (g >= ng) { wp[g] = wn[g] = 0; deri[g] = 0; continue; }
                 T sl[EPL];
 #pragma unroll
                 for (int j = 0; j < EPL; j++) sl[j] = 0;
@@ -660,7 +678,6 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 
                 // sp / sn become the two distance vectors from here on.  Their squared lengths grow with the history (|S|^0.8
                 // at alpha = -0.6) and x_uij is their difference: formed and subtracted in fp64, or a history of thousands of
                 // items costs f32 tables 1e-4 in x_uij
-                const double wpd = cp[g] > 0 ? pow((double)cp[g], (double)m.alpha) : 0.0, wnd = cn[g] > 0 ? pow((double)cn[g], (double)m.alpha) : 0.0;
                 double qd = 0;
 #pragma unroll
                 for (int j = 0; j < EPL; j++) {
