@@ -431,8 +431,8 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     // are what bounds the kernels.  Fossil / FossilSimple (every step rewrites the user's whole training sequence): four
     // tuples where the mean history is >= 32 clicks, eight where it is >= 64; REBUS (the tuples of a group end at different
     // positions, the walk is the longest prefix): four from a mean of 32.  1M users x 200k items x 100M clicks (mean 98),
-    // ms per epoch for two / four / eight tuples per walk: Fossil 1230 / 612 / 438, FossilSimple - / 633 / 364, REBUS 713 /
-    // 565 / 531.  On a 5.9M-step corpus with that catalog the best-validation test AUC ends, against the sequential fp64
+    // ms per epoch for two / four / eight tuples per walk (before the table of weights, which took another 40 .. 125 ms off the
+    // defaults): Fossil 1230 / 612 / 438, FossilSimple - / 633 / 364, REBUS 713 / 565 / 531.  On a 5.9M-step corpus with that catalog the best-validation test AUC ends, against the sequential fp64
     // run: Fossil +0.0025 / +0.0017 / +0.0007, FossilSimple +0.0014 / +0.0009 / -0.0005, REBUS +0.0005 / +0.0008 / +0.0014
     // (HIT@50 -0.0009 / -0.0004 / -0.006); tests/test_gpu_seq_anchor.py holds the default to 0.005.
     if (e->user_batch == 2 && mean_history >= 32.0)

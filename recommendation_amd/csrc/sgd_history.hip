@@ -17,9 +17,9 @@
 // plus the row's own regulariser term - one multiply-add per row; the few other rows go through the
 // per-tuple case analysis of the reference.  All G tuples see the parameters as they were when the
 // group started, which is what tuples in flight on different wavefronts see of each other anyway.
-// What bounds the kernels at 1M users x 200k items x 100M clicks, K = 64, f32 (PMC): REBUS, two
-// tuples per walk, the float atomics (0.92 of the 1.3 TB/s the memory side executes them at); Fossil /
-// FossilSimple, eight per walk, the per-tuple work outside the walks (atomics at 0.5 / 0.6 of that
+// What bounds the kernels at 1M users x 200k items x 100M clicks, K = 64, f32 (PMC): REBUS, four
+// tuples per walk, the float atomics (0.91 of the 1.3 TB/s the memory side executes them at); Fossil /
+// FossilSimple, eight per walk, the per-tuple work outside the walks (atomics at 0.7 / 0.8 of that
 // rate).  Float atomics on the few most clicked rows run far below that rate (thousands of adds queue
 // on one address: all-atomics costs REBUS 4x the time per epoch): those rows are plain stores.
 // Parameters that every tuple touches are not scattered per tuple (their atomics would all hit one
