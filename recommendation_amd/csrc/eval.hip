@@ -162,13 +162,28 @@ __global__ void __launch_bounds__(256) build_queries_kernel(DevModel m, EvalDev 
 #pragma unroll
         for (int j = 0; j < E; j++) sall[j] = sex[j] = 0;
         int cex = 0;
-        for (int t = 0; t < n; t++) {
-            const int it = seq[t];
-            if (it != pos) cex++;
+        // eight positions per round: their ids in one load (lane q fetches position t0 + q), their rows requested together,
+        // then added in the order of the sequence - one position at a time cost two memory round trips per row
+        const T* tabUi = (const T*)m.tab[tUi];
+        for (int t0 = 0; t0 < n; t0 += 8) {
+            const int idv = seq[t0 + lane < n ? t0 + lane : n - 1];
+            int its[8]; T x[8][E];
 #pragma unroll
-            for (int j = 0; j < E; j++) {
-                const int k = lane + 64 * j;
-                if (k < K) { const double x = B.ld(tUi, it, K, k); sall[j] += x; if (it != pos) sex[j] += x; }
+            for (int q = 0; q < 8; q++) {
+                its[q] = __builtin_amdgcn_readlane(idv, q);
+#pragma unroll
+                for (int j = 0; j < E; j++) { const int k = lane + 64 * j; x[q][j] = tabUi[(int64_t)its[q] * K + (k < K ? k : K - 1)]; }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                if (t0 + q >= n) break;
+                const int it = its[q];
+                if (it != pos) cex++;
+#pragma unroll
+                for (int j = 0; j < E; j++) {
+                    const int k = lane + 64 * j;
+                    if (k < K) { const double xv = (double)x[q][j]; sall[j] += xv; if (it != pos) sex[j] += xv; }
+                }
             }
         }
         const double wall = n > 0 ? pow((double)n, -0.2) : 0, wex = cex > 0 ? pow((double)cex, -0.2) : 0;
@@ -208,7 +223,6 @@ __global__ void __launch_bounds__(256) build_queries_kernel(DevModel m, EvalDev 
         break;
     }
     case REC_REBUS: {  // REBUS.cpp:205-269 with the contexts of REBUS.cpp:758-782
-        const uint8_t* fo = m.first_occ + so;
         const int64_t cid = so + 2 * (int64_t)u + (n - 1) + ctx;
         const int32_t* path = m.path_item + m.path_off[cid]; const int np = (int)(m.path_off[cid + 1] - m.path_off[cid]);
         const double* etas = m.eta + (int64_t)np * m.L;
@@ -218,14 +232,40 @@ __global__ void __launch_bounds__(256) build_queries_kernel(DevModel m, EvalDev 
 #pragma unroll
         for (int j = 0; j < E; j++) sall[j] = sex[j] = ss[j] = 0;
         int call = 0, cex = 0;
-        for (int t = 0; t < n + (extra ? 1 : 0); t++) {
-            if (t < n && !fo[t]) continue;
-            const int it = t < n ? seq[t] : val;
-            call++; if (it != pos) cex++;
+        // the first occurrences of the sequence from the packed list the training kernel walks ({item, position} in the order
+        // of the sequence, {0, INT_MAX} after the last one), eight per round: ids in one load (lane q fetches entry t0 + q),
+        // rows requested together, added in the order of the sequence; then the validation item where it joins the set
+        const T* tabP = (const T*)m.tab[RB_P];
+        const int2* kept = (const int2*)(m.kept_pair + 2 * so);
+        bool more = true;
+        for (int t0 = 0; more && t0 < n; t0 += 8) {
+            const int2 ev2 = kept[t0 + lane < n ? t0 + lane : n - 1];
+            const int idv = (t0 + lane < n && ev2.y != 0x7fffffff) ? ev2.x : -1;
+            int its[8]; T x[8][E];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                its[q] = __builtin_amdgcn_readlane(idv, q);
+#pragma unroll
+                for (int j = 0; j < E; j++) { const int k = lane + 64 * j; x[q][j] = tabP[(int64_t)(its[q] > 0 ? its[q] : 0) * K + (k < K ? k : K - 1)]; }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int it = its[q];
+                if (it < 0) { more = false; break; }
+                call++; if (it != pos) cex++;
+#pragma unroll
+                for (int j = 0; j < E; j++) {
+                    const int k = lane + 64 * j;
+                    if (k < K) { const double xv = (double)x[q][j]; sall[j] += xv; if (it != pos) sex[j] += xv; }
+                }
+            }
+        }
+        if (extra) {
+            call++; if (val != pos) cex++;
 #pragma unroll
             for (int j = 0; j < E; j++) {
                 const int k = lane + 64 * j;
-                if (k < K) { const double x = B.ld(RB_P, it, K, k); sall[j] += x; if (it != pos) sex[j] += x; }
+                if (k < K) { const double xv = B.ld(RB_P, val, K, k); sall[j] += xv; if (val != pos) sex[j] += xv; }
             }
         }
         const double wall = call > 0 ? pow((double)call, m.alpha) : 0, wex = cex > 0 ? pow((double)cex, m.alpha) : 0;
