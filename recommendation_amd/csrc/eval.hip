@@ -1238,8 +1238,12 @@ __global__ void __launch_bounds__(256) correct_clicked_kernel(DevModel m, EvalDe
     const int32_t* open = ev.amb ? ev.amb + (int64_t)w * ev.amb_cap : nullptr;
     const int total = nc + 2 + na;
     int dc = 0, dc2 = 0;
-    for (int base = 0; base < total; base += 4) {
-        const int idx = base + gq;
+    // Sixteen entries of the list per round: lane l decodes entry base + (l & 15), then the four groups of 16 lanes score
+    // entries 4s + group for s = 0 .. 3 - the rows of all four requested together (one entry at a time a round cost two
+    // memory round trips: the id, then its row).  Each score is summed as before: k ascending within the 16 lanes, then
+    // across them.
+    for (int base = 0; base < total; base += 16) {
+        const int idx = base + l16;
         int e = -1, wgt = 0, which = 3;
         if (idx < nc) {
             e = clk[idx];
@@ -1255,18 +1259,39 @@ __global__ void __launch_bounds__(256) correct_clicked_kernel(DevModel m, EvalDe
             e = ent & 0x0fffffff; which = ent >> 28; wgt = 1;
         }
         if (!__ballot(wgt != 0)) continue;
-        const int64_t ec = (wgt != 0 && e >= 0) ? e : 0;   // a group without work still runs the loads, on item 0
-        double s = 0;
-        if (l1) {
-            for (int k = l16; k < K1; k += 16) s += fabs(q[k] - (double)seg0[ec * K1 + k]);
-            s = -(ev.bconst[ec] + group_sum<16>(s));
-        } else {
-            for (int k = l16; k < K1; k += 16) s += q[k] * (double)seg0[ec * K1 + k];
-            for (int k = l16; k < K2; k += 16) s += q[K1 + k] * (double)seg1[ec * K2 + k];
-            s = group_sum<16>(s) + ev.bconst[ec];
+        int ws[4], whs[4]; int64_t ec[4]; double acc[4];
+#pragma unroll
+        for (int sb = 0; sb < 4; sb++) {
+            const int src = 4 * sb + gq;
+            const int es = __shfl(e, src, 64);
+            ws[sb] = __shfl(wgt, src, 64); whs[sb] = __shfl(which, src, 64);
+            ec[sb] = (ws[sb] != 0 && es >= 0) ? es : 0;   // an entry without work still runs the loads, on item 0
+            acc[sb] = 0;
         }
-        dc += ((which & 1) && thr > s) ? wgt : 0;
-        dc2 += ((which & 2) && thr2 > s) ? wgt : 0;
+        if (l1) {
+            for (int k = l16; k < K1; k += 16) {
+                const double qk = q[k];
+#pragma unroll
+                for (int sb = 0; sb < 4; sb++) acc[sb] += fabs(qk - (double)seg0[ec[sb] * K1 + k]);
+            }
+        } else {
+            for (int k = l16; k < K1; k += 16) {
+                const double qk = q[k];
+#pragma unroll
+                for (int sb = 0; sb < 4; sb++) acc[sb] += qk * (double)seg0[ec[sb] * K1 + k];
+            }
+            for (int k = l16; k < K2; k += 16) {
+                const double qk = q[K1 + k];
+#pragma unroll
+                for (int sb = 0; sb < 4; sb++) acc[sb] += qk * (double)seg1[ec[sb] * K2 + k];
+            }
+        }
+#pragma unroll
+        for (int sb = 0; sb < 4; sb++) {
+            const double sc = l1 ? -(ev.bconst[ec[sb]] + group_sum<16>(acc[sb])) : group_sum<16>(acc[sb]) + ev.bconst[ec[sb]];
+            dc += ((whs[sb] & 1) && thr > sc) ? ws[sb] : 0;
+            dc2 += ((whs[sb] & 2) && thr2 > sc) ? ws[sb] : 0;
+        }
     }
     // every lane of a group holds the group's sum: add the four groups
     dc = dc + __shfl_xor(dc, 16, 64); dc = dc + __shfl_xor(dc, 32, 64);
