@@ -406,11 +406,12 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
     // Fossil's global weights move by lr/10 per step with a small curvature: a larger budget than TransRec's r
     if (d->model == REC_FOSSIL || d->model == REC_FOSSIL_SIMPLE) {
         e->global_cap = 4096;
-        // A launch is at most 1/64 of an epoch (and 2^18 .. 2^22 tuples): every launch ends on its longest history, so short
-        // launches lose to their tails.  1M users x 200k items x 100M clicks, launches of 2^18 / 2^20 / 2^22 tuples: 0.70 /
-        // 0.61 / 0.59 s per epoch, test AUC after one to four epochs equal within its seed-to-seed spread of 0.002
+        // A launch is at most 1/32 of an epoch (and 2^18 .. 2^22 tuples): every launch ends on its longest history, so short
+        // launches lose to their tails.  1M users x 200k items x 100M clicks, launches of 2^18 / 2^20 / 2^21 / 2^22 tuples:
+        // 0.70 / 0.61 / - / 0.59 s per epoch with four tuples per walk, - / 0.400 / 0.386 / 0.380 s with the final kernel; test
+        // AUC after one to four epochs equal within its seed-to-seed spread of 0.002 for 2^18, 2^20 and 2^22
         // (scripts/exp_fossil_window.py).
-        while (e->global_window < (1 << 22) && e->global_window * 2 * 64 <= e->steps_per_epoch) e->global_window *= 2;
+        while (e->global_window < (1 << 22) && e->global_window * 2 * 32 <= e->steps_per_epoch) e->global_window *= 2;
     }
     // TransRec's global translation r barely depends on the launch length (200k x 50k corpus: the same AUC trajectory
     // within 0.003 for launches of 2^16 .. 3*10^7 tuples), and longer launches lose less to ramp-up and tails
