@@ -224,10 +224,11 @@ __device__ __forceinline__ int special_items(const int (&shortl)[G], const int (
     return spec;
 }
 
-// (f32, K <= 64, one or two tuples per walk: held to 128 registers, four wavefronts per SIMD; more wavefronts did not
-// pay for four tuples per walk: 614 ms per epoch at three or at four per SIMD)
+// (f32, K <= 64: one or two tuples per walk held to 128 registers, four wavefronts per SIMD; Fossil / FossilSimple with eight
+// per walk to 168, three per SIMD, for ten spilled registers: Fossil 387 -> 327 ms per epoch at 1M users x 200k items,
+// FossilSimple unchanged; at 128 registers both lose 30 .. 90 ms to the spills)
 template <int MODEL, class T, int EPL, int G>
-__global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 4 : 1) sgd_history_batch_kernel(DevModel m, const int4* __restrict__ tuples, int64_t n, T lr, int atomic, int CLAIM)
+__global__ void __launch_bounds__(256, (sizeof(T) == 4 && EPL == 1 && G <= 2) ? 4 : (sizeof(T) == 4 && EPL == 1 && G == 8 && MODEL != REC_REBUS) ? 3 : 1) sgd_history_batch_kernel(DevModel m, const int4* __restrict__ tuples, int64_t n, T lr, int atomic, int CLAIM)
 {
     constexpr int RIF = EPL == 1 ? 8 : 4;   // history rows per round
     const int lane = threadIdx.x & 63;
