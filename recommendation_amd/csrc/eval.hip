@@ -1143,21 +1143,68 @@ __global__ void __launch_bounds__(256) score_count_l1_kernel(EvalDev ev, const T
         const int64_t qi = qbase + qg + NG * a;
         thr[a] = ev.thr[qi]; ex1[a] = qtest[qi]; ex2[a] = qval[qi]; cnt[a] = 0;
     }
+    // A tile is a contiguous stretch of the item table.  Up to PF elements per thread, the next tile is requested into
+    // registers before the current one is scored and stored to LDS afterwards: staged where it is needed, every tile waited
+    // for its loads with nothing else to do (two barriers per tile) - about 40 % of the sweep.
+    constexpr int PF = 16;
+    const bool ahead = TI * K <= 256 * PF;
+    T pre[PF]; int lofs[PF];
+#pragma unroll
+    for (int e = 0; e < PF; e++) { const int i = tid + 256 * e; lofs[e] = i < TI * K ? (i / K) * STR + i % K : -1; pre[e] = 0; }
+    auto request = [&](int item0) {
+        const int64_t base = (int64_t)item0 * K, end = (int64_t)I * K;
+#pragma unroll
+        for (int e = 0; e < PF; e++) { const int64_t g = base + tid + 256 * e; pre[e] = (lofs[e] >= 0 && g < end) ? H[g] : (T)0; }
+    };
+    if (ahead) request(0);
     for (int item0 = 0; item0 < I; item0 += TI) {
         __syncthreads();
-        for (int i = tid; i < TI * K; i += 256) {
-            const int it = i / K, k = i % K; const int64_t j = (int64_t)item0 + it;
-            tile[it * STR + k] = j < I ? (double)H[j * K + k] : 0.0;
+        if (ahead) {
+#pragma unroll
+            for (int e = 0; e < PF; e++) if (lofs[e] >= 0) tile[lofs[e]] = (double)pre[e];
+        } else {
+            for (int i = tid; i < TI * K; i += 256) {
+                const int it = i / K, k = i % K; const int64_t j = (int64_t)item0 + it;
+                tile[it * STR + k] = j < I ? (double)H[j * K + k] : 0.0;
+            }
         }
         __syncthreads();
+        if (ahead && item0 + TI < I) request(item0 + TI);
         const int j = item0 + jj;
         double acc[QPT];
 #pragma unroll
         for (int a = 0; a < QPT; a++) acc[a] = 0;
-        for (int k = 0; k < K; k++) {
-            const double t = tile[jj * STR + k];
+        if constexpr (TI == 64) {
+            // a wavefront is one query group: its QPT queries are the same on every lane.  Read from the query array with a
+            // wave-uniform address they arrive in scalar registers (scalar loads, four components at a time) instead of
+            // through LDS - nine LDS reads per component and wavefront (one tile value, eight broadcast query values) against
+            // sixteen fp64 vector operations left LDS the bound, at 2.3x the vector floor
+            const int qgu = __builtin_amdgcn_readfirstlane(qg);
+            // (the constant address space: the array is not written while this kernel runs, and only loads from that space
+            // are issued as scalar loads when their address is wave-uniform)
+            typedef const __attribute__((address_space(4))) double* const_double_ptr;
+            const_double_ptr qrow = (const_double_ptr)(uintptr_t)(ev.Q + (qbase + qgu) * ev.KQ);
+            const int64_t qstep = (int64_t)NG * ev.KQ;
+            int k = 0;
+            for (; k + 4 <= K; k += 4) {
+                const double t0 = tile[jj * STR + k], t1 = tile[jj * STR + k + 1], t2 = tile[jj * STR + k + 2], t3 = tile[jj * STR + k + 3];
 #pragma unroll
-            for (int a = 0; a < QPT; a++) acc[a] += fabs(qs[(qg + NG * a) * K + k] - t);
+                for (int a = 0; a < QPT; a++) {
+                    const_double_ptr qa = qrow + a * qstep + k;
+                    acc[a] += fabs(qa[0] - t0); acc[a] += fabs(qa[1] - t1); acc[a] += fabs(qa[2] - t2); acc[a] += fabs(qa[3] - t3);
+                }
+            }
+            for (; k < K; k++) {
+                const double t = tile[jj * STR + k];
+#pragma unroll
+                for (int a = 0; a < QPT; a++) acc[a] += fabs(qrow[a * qstep + k] - t);
+            }
+        } else {
+            for (int k = 0; k < K; k++) {
+                const double t = tile[jj * STR + k];
+#pragma unroll
+                for (int a = 0; a < QPT; a++) acc[a] += fabs(qs[(qg + NG * a) * K + k] - t);
+            }
         }
         if (j < I) {
             const double bj = ev.col_b[j];
