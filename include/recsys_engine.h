@@ -281,7 +281,8 @@ int rec_project_rows(rec_engine* e);
  *                   with fewer are applied one after the other by the same wavefront, each seeing the one before it
  *   "stale_window"  tuples per update launch for small catalogs (0 = no limit)
  *   "global_window" tuples per update launch for models with a row every tuple touches (default 2^22 for TransRec; for
- *                   Fossil / FossilSimple 1/32 of an epoch within 2^18 .. 2^22)
+ *                   Fossil / FossilSimple 1/32 of an epoch within 2^18 .. 2^22,
+ *                   a quarter of an epoch shorter than 2^18 steps)
  *   "global_cap"    such a row moves by at most this many steps' worth of learning rate per launch
  *   "eval_screen"   with f32 tables the full-catalog sweep of rec_eval runs on a matrix pipe narrower than fp64 and decides every
  *                   comparison it can prove from a rounding bound; the columns within the bound of a threshold are decided in

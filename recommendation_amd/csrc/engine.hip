@@ -408,10 +408,18 @@ extern "C" int rec_create(const rec_corpus* c, const rec_model_desc* d, rec_engi
         e->global_cap = 4096;
         // A launch is at most 1/32 of an epoch (and 2^18 .. 2^22 tuples): every launch ends on its longest history, so short
         // launches lose to their tails.  1M users x 200k items x 100M clicks, launches of 2^18 / 2^20 / 2^21 / 2^22 tuples:
-        // 0.70 / 0.61 / - / 0.59 s per epoch with four tuples per walk, - / 0.400 / 0.386 / 0.380 s with the final kernel; test
-        // AUC after one to four epochs equal within its seed-to-seed spread of 0.002 for 2^18, 2^20 and 2^22
-        // (scripts/exp_fossil_window.py).
+        // 0.70 / 0.61 / - / 0.59 s per epoch with four tuples per walk, - / 0.400 / 0.386 / 0.380 s with eight; test AUC after
+        // one to four epochs equal within its seed-to-seed spread of 0.002 for 2^18, 2^20 and 2^22
+        // (scripts/exp_fossil_window.py).  Shorter launches are no better for the global row either: on the 12k-user corpus
+        // (600k steps per epoch) launches of 4096 / 18 750 / 65 536 / 262 144 tuples end 0.014 / 0.0045 / 0.0003 / 0.0001 below
+        // the reference's best test AUC (scripts/exp_mid_variants.py Fossil "global_window=...").
         while (e->global_window < (1 << 22) && e->global_window * 2 * 32 <= e->steps_per_epoch) e->global_window *= 2;
+        // An epoch shorter than a launch would move the global rows once per EPOCH, by global_cap steps' worth: 4.4 times less
+        // than the reference's per-step updates over the 18 097 steps of an ML-5 epoch, and FossilSimple ended 0.004 of test AUC
+        // ABOVE the reference's mean of five seeds.  Such an epoch runs as four launches instead: ML-5 at 4524 tuples a launch
+        // ends within 0.001 (FossilSimple) and 0.002 (Fossil, L = 3) of that mean; two launches of 9048 leave Fossil 0.005
+        // below it, and one launch with twice the budget 0.006 below (scripts/exp_converged_key.py MODEL 2 global_window=...).
+        if (e->steps_per_epoch < e->global_window) e->global_window = std::max<int64_t>(e->global_cap, e->steps_per_epoch / 4);
     }
     // TransRec's global translation r barely depends on the launch length (200k x 50k corpus: the same AUC trajectory
     // within 0.003 for launches of 2^16 .. 3*10^7 tuples), and longer launches lose less to ramp-up and tails

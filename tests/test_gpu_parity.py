@@ -877,13 +877,16 @@ def _check_hit50(key, refs, got):
 @pytest.mark.parametrize("key", sorted(_traj_groups()))
 def test_converged_auc_within_0_005_of_reference(key):
     """Criterion (c).  Reference side: its own oneiteration + AUC on ML-5 (K=10), best-validation
-    checkpoint of the trajectory, two srand seeds.  Engine side: device sampler + Hogwild update with the
-    same epochs and evaluation cadence, two seeds.  Bound: |mean test AUC difference| <= 0.005."""
+    checkpoint of the trajectory, five distinct srand seeds.  Engine side: device sampler + Hogwild update with the
+    same epochs and evaluation cadence, four seeds.  Bound: |mean test AUC difference| <= 0.005.
+    (Single runs of one configuration spread by up to 0.008 on either side - TransRec_L1, whose step is a sign: engine
+    0.7356 .. 0.7428, reference 0.7384 .. 0.7446; HRM_max: reference 0.7463 .. 0.7542 - so with two runs a side, as this
+    test had it first, the means of the noisiest configurations sat up to 0.005 apart by chance.)"""
     from tests.converge_util import best_of_trajectory
     refs = _traj_groups()[key]
     ref_test = np.mean([r["auc_test_at_best"] for r in refs])
     ref_val = np.mean([r["best_auc_val"] for r in refs])
-    got = [best_of_trajectory(refs[0], seed=s) for s in (0, 1)]
+    got = [best_of_trajectory(refs[0], seed=s) for s in (0, 1, 2, 3)]
     test_auc = np.mean([g["auc_test_at_best"] for g in got])
     val_auc = np.mean([g["best_auc_val"] for g in got])
     assert abs(test_auc - ref_test) <= 0.005, (key, test_auc, ref_test)
@@ -904,7 +907,7 @@ def test_converged_auc_with_shared_negatives_within_0_005_of_reference(key):
     refs = _traj_groups()[key]
     ref_test = np.mean([r["auc_test_at_best"] for r in refs])
     ref_val = np.mean([r["best_auc_val"] for r in refs])
-    got = [best_of_trajectory(refs[0], seed=s, options={"share_negative": 2}) for s in (0, 1)]
+    got = [best_of_trajectory(refs[0], seed=s, options={"share_negative": 2}) for s in (0, 1, 2, 3)]
     test_auc = np.mean([g["auc_test_at_best"] for g in got])
     val_auc = np.mean([g["best_auc_val"] for g in got])
     assert abs(test_auc - ref_test) <= 0.005, (key, test_auc, ref_test)
