@@ -1121,14 +1121,93 @@ __global__ void __launch_bounds__(256) screen_margins_kernel(EvalDev ev, const u
     }
 }
 
+// doubles as unsigned keys that order like the doubles (every real number and both infinities map to a key above 0)
+__device__ __forceinline__ uint64_t order_key(double x)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double order_unkey(uint64_t k)
+{
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
+}
+
+// Top-k lists out of the |.|_1 sweep.  The scores of that sweep are the exact fp64 scores already, so a query's list holds
+// (score, item) and its bar is simply the k-th best score listed so far (clicked items left out): no margins, no rescoring.
+// A wavefront of the sweep is 64 items against the same queries, so a list belongs to one wavefront - appended to with a
+// ballot, no atomics - and when fewer than 64 places are left the wavefront selects the k-th best of it (a search over the
+// 64 bits of the keys, counted with ballots), drops what is below and what the user has clicked, and raises the bar.
+// More than L1_LIST - 64 entries tied at the k-th best: the query is left to the score-matrix path.
+#define L1_LIST 256
+struct TopkL1Dev {
+    int k;
+    double* cand_s;             // [nq_pad][L1_LIST]
+    int32_t* cand_i;            // [nq_pad][L1_LIST]
+    int32_t* cand_cnt;          // [nq_pad]
+    int32_t* q_over;            // [nq_pad] 1: ties the list could not hold
+    const int4* qmeta;          // [nq_pad] (user, positive, the other held-out item, -); user -1 on padding rows
+    const int64_t* clk_off; const int32_t* clk_item;
+    int32_t* items_out;         // [nq][k]
+    double* scores_out;         // [nq][k]
+};
+
+// n: entries in the list of query qi (wave-uniform); returns the new bar
+__device__ __forceinline__ double l1_list_select(const TopkL1Dev& tk, int64_t qi, int& n, int lane)
+{
+    double* cs = tk.cand_s + qi * L1_LIST; int32_t* ci = tk.cand_i + qi * L1_LIST;
+    const int user = tk.qmeta[qi].x;
+    const int32_t* clk = tk.clk_item + tk.clk_off[user]; const int nc = (int)(tk.clk_off[user + 1] - tk.clk_off[user]);
+    __threadfence();                           // the appends of this wavefront have reached memory
+    double sc[L1_LIST / 64]; int it[L1_LIST / 64]; uint64_t key[L1_LIST / 64];
+#pragma unroll
+    for (int i = 0; i < L1_LIST / 64; i++) {
+        const int idx = lane + 64 * i;
+        // loads that do not stop at this compute unit's vector cache (which may hold the lines as an earlier selection read them)
+        sc[i] = idx < n ? __hip_atomic_load(cs + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        it[i] = idx < n ? __hip_atomic_load(ci + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < L1_LIST / 64; i++) {
+        const bool ok = lane + 64 * i < n && !sorted_contains(clk, nc, it[i]);
+        key[i] = ok ? order_key(sc[i]) : 0ull;
+    }
+    uint64_t prefix = 0;                       // the largest v with at least k keys >= v (0: fewer than k candidates)
+#pragma unroll 1
+    for (int bit = 63; bit >= 0; bit--) {
+        const uint64_t v = prefix | (1ull << bit);
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < L1_LIST / 64; i++) c += __popcll(__ballot(key[i] >= v));
+        if (c >= tk.k) prefix = v;
+    }
+    int off = 0;
+#pragma unroll
+    for (int i = 0; i < L1_LIST / 64; i++) {
+        const bool keep = key[i] != 0ull && key[i] >= prefix;
+        const unsigned long long bal = __ballot(keep);
+        if (keep) { const int at = off + __popcll(bal & ((1ull << lane) - 1ull)); cs[at] = sc[i]; ci[at] = it[i]; }
+        off += __popcll(bal);
+    }
+    double nb = prefix ? order_unkey(prefix) : -INFINITY;
+    if (off > L1_LIST - 64) {
+        if (lane == 0) tk.q_over[qi] = 1;
+        off = 0; nb = INFINITY;
+    }
+    n = off;
+    return nb;
+}
+
 // |.|_1 scoring (TransRec_L1): not a contraction, so it runs on the vector ALU.  A block owns QT
 // queries for the whole item sweep; items are staged through LDS in tiles of 64 (odd row stride:
 // conflict-free when the 64 lanes of a wavefront read 64 different items), thread (item jj, query
 // group qg) accumulates QT/4 distances per tile.
-template <class T, int QT, int TI, bool STORE>
+// MODE 0: counts against the queries' thresholds; 1: the scores themselves, to ev.S; 2: top-k lists (TI == 64 only)
+template <class T, int QT, int TI, int MODE>
 __global__ void __launch_bounds__(256) score_count_l1_kernel(EvalDev ev, const T* __restrict__ H, const int32_t* __restrict__ qtest,
-                                                             const int32_t* __restrict__ qval, int I, int K)
+                                                             const int32_t* __restrict__ qval, int I, int K, TopkL1Dev tk)
 {
+    constexpr bool STORE = MODE == 1;
+    static_assert(MODE != 2 || TI == 64, "a list belongs to one wavefront");
     constexpr int NG = 256 / TI, QPT = QT / NG;   // query groups per block, queries per thread
     extern __shared__ double lds[];
     const int STR = K | 1;
@@ -1141,7 +1220,13 @@ __global__ void __launch_bounds__(256) score_count_l1_kernel(EvalDev ev, const T
 #pragma unroll
     for (int a = 0; a < QPT; a++) {
         const int64_t qi = qbase + qg + NG * a;
-        thr[a] = ev.thr[qi]; ex1[a] = qtest[qi]; ex2[a] = qval[qi]; cnt[a] = 0;
+        if constexpr (MODE == 2) {
+            // the bar of a list; a padding row lists nothing
+            const int4 meta = tk.qmeta[qi];
+            thr[a] = meta.x >= 0 ? -INFINITY : INFINITY; ex1[a] = meta.y; ex2[a] = meta.z; cnt[a] = 0;
+        } else {
+            thr[a] = ev.thr[qi]; ex1[a] = qtest[qi]; ex2[a] = qval[qi]; cnt[a] = 0;
+        }
     }
     // A tile is a contiguous stretch of the item table.  Up to PF elements per thread, the next tile is requested into
     // registers before the current one is scored and stored to LDS afterwards: staged where it is needed, every tile waited
@@ -1206,7 +1291,51 @@ __global__ void __launch_bounds__(256) score_count_l1_kernel(EvalDev ev, const T
                 for (int a = 0; a < QPT; a++) acc[a] += fabs(qs[(qg + NG * a) * K + k] - t);
             }
         }
-        if (j < I) {
+        if constexpr (MODE == 2) {
+            const bool inr = j < I;
+            const double bj = inr ? ev.col_b[j] : 0.0;
+            const int jid = inr ? (ev.col_item ? ev.col_item[j] : j) : -1;
+            bool crowded = false;
+#pragma unroll
+            for (int a = 0; a < QPT; a++) {
+                const double sc = -(bj + acc[a]) + 0.0;       // (+ 0.0: one zero, so that keys order exactly like the scores)
+                const bool in = inr && jid != ex1[a] && jid != ex2[a] && sc >= thr[a];
+                const unsigned long long bal = __ballot(in);
+                if (bal) {
+                    const int64_t qi = qbase + qg + NG * a;
+                    if (in) {
+                        const int at = cnt[a] + __popcll(bal & ((1ull << jj) - 1ull));
+                        tk.cand_s[qi * L1_LIST + at] = sc; tk.cand_i[qi * L1_LIST + at] = jid;
+                    }
+                    cnt[a] += __popcll(bal);
+                    crowded |= cnt[a] > L1_LIST - 64;
+                }
+            }
+            // (selections after the tile's appends, where the accumulators are dead: called from inside the loop above
+            // they doubled the kernel's registers)
+            // ONE copy of the selection code, its query picked at run time: counts and bars go through LDS for it (the query
+            // rows of LDS, which this tile shape does not read - its queries arrive through scalar loads); unrolled over
+            // the queries it cost 90 more registers
+            if (crowded) {
+                double* sw = qs + qg * (2 * QPT);
+                if (jj == 0) {
+#pragma unroll
+                    for (int a = 0; a < QPT; a++) { sw[2 * a] = (double)cnt[a]; sw[2 * a + 1] = thr[a]; }
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+                for (int a = 0; a < QPT; a++) {
+                    int n = (int)sw[2 * a];
+                    if (n > L1_LIST - 64) {
+                        const double nb = l1_list_select(tk, qbase + qg + NG * a, n, jj);
+                        if (jj == 0) { sw[2 * a] = (double)n; sw[2 * a + 1] = nb; }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int a = 0; a < QPT; a++) { cnt[a] = (int)sw[2 * a]; thr[a] = sw[2 * a + 1]; }
+            }
+        } else if (j < I) {
             const double bj = ev.col_b[j];
             const int jid = ev.col_item ? ev.col_item[j] : j;
 #pragma unroll
@@ -1215,6 +1344,11 @@ __global__ void __launch_bounds__(256) score_count_l1_kernel(EvalDev ev, const T
                 else cnt[a] += (jid != ex1[a] && jid != ex2[a] && thr[a] > -(bj + acc[a])) ? 1 : 0;
             }
         }
+    }
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int a = 0; a < QPT; a++) if (jj == 0) tk.cand_cnt[qbase + qg + NG * a] = cnt[a];
+        return;
     }
     if (STORE) return;
 #pragma unroll
@@ -1227,17 +1361,19 @@ __global__ void __launch_bounds__(256) score_count_l1_kernel(EvalDev ev, const T
 }
 
 // launches the L1 scorer with the item tile that fits the 160 KB of LDS: 64 items up to K = 160, 32 above
-template <class T, bool STORE>
-static int launch_score_l1(const EvalDev& ev, const T* H, const int32_t* qtest, const int32_t* qval, int n_cols, int K, hipStream_t st)
+template <class T, int MODE>
+static int launch_score_l1(const EvalDev& ev, const T* H, const int32_t* qtest, const int32_t* qval, int n_cols, int K, hipStream_t st,
+                           const TopkL1Dev& tk = TopkL1Dev{})
 {
     constexpr int QT = 32;
     const unsigned blocks = (unsigned)(ev.nq_pad / QT);
     if (K <= 160) {
         const size_t lds_bytes = sizeof(double) * ((size_t)64 * (K | 1) + (size_t)QT * K);
-        hipLaunchKernelGGL((score_count_l1_kernel<T, QT, 64, STORE>), dim3(blocks), dim3(256), lds_bytes, st, ev, H, qtest, qval, n_cols, K);
+        hipLaunchKernelGGL((score_count_l1_kernel<T, QT, 64, MODE>), dim3(blocks), dim3(256), lds_bytes, st, ev, H, qtest, qval, n_cols, K, tk);
     } else {
         const size_t lds_bytes = sizeof(double) * ((size_t)32 * (K | 1) + (size_t)QT * K);
-        hipLaunchKernelGGL((score_count_l1_kernel<T, QT, 32, STORE>), dim3(blocks), dim3(256), lds_bytes, st, ev, H, qtest, qval, n_cols, K);
+        if constexpr (MODE == 2) { rec_set_error("top-k lists out of the L1 sweep need K <= 160"); return -1; }
+        else hipLaunchKernelGGL((score_count_l1_kernel<T, QT, 32, MODE>), dim3(blocks), dim3(256), lds_bytes, st, ev, H, qtest, qval, n_cols, K, tk);
     }
     if (hipGetLastError() != hipSuccess) { rec_set_error("launch of the L1 scoring kernel failed"); return -2; }
     return 0;
@@ -1713,7 +1849,7 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
                             : launch_screen<false>(ev, (const float*)seg0_cols, (const float*)seg1_cols, NC, qtest, qval, st);
     };
     if (l1) {
-        rc = launch_score_l1<T, false>(ev, seg0_cols, qtest, qval, NC, m.K, st);
+        rc = launch_score_l1<T, 0>(ev, seg0_cols, qtest, qval, NC, m.K, st);
     } else if (screen16) {
         // operands as pairs of f16 halves under two power-of-two scales, margins, sweep on the 16-bit matrix pipe
         const int NI16 = KQ16 <= 128 ? 64 : 32;
@@ -1861,11 +1997,6 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
 // clicked / held-out items are masked, the context's positive enters with the score the reference
 // formula gives it, and one block per row selects the k largest by an 8-pass radix select on
 // order-preserving 64-bit keys, then orders them (score descending, item id ascending on ties).
-__device__ __forceinline__ uint64_t order_key(double x)
-{
-    const uint64_t b = (uint64_t)__double_as_longlong(x);
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
 
 __global__ void __launch_bounds__(256) topk_mask_kernel(DevModel m, EvalDev ev)
 {
@@ -1975,8 +2106,11 @@ static int topk_impl(const DevModel& m0, const int32_t* users_host, int n_users,
     constexpr int L1_QT = 32;
     const int mt = ev.KQ <= 32 ? 4 : ev.KQ <= 64 ? 2 : 1;
     const int qblock = l1 ? L1_QT : 4 * mt * 16;
-    // rows of one batch: at most 2 GiB of scores
-    int batch_users = (int)std::max<int64_t>(1, std::min<int64_t>(4096, ((int64_t)1 << 31) / ((int64_t)I * 8) / 2));
+    // rows of one batch: a quarter of the free device memory in scores, within 2 .. 16 GiB (a batch of a few hundred rows
+    // leaves most of the chip idle: the scoring kernels launch one block per 32 .. 128 rows)
+    size_t free_b = 0, total_b = 0; (void)hipMemGetInfo(&free_b, &total_b);
+    const int64_t score_bytes = std::min<int64_t>(std::max<int64_t>((int64_t)(free_b / 4), (int64_t)1 << 31), (int64_t)1 << 34);
+    int batch_users = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(4096, n_users), score_bytes / ((int64_t)I * 8) / 2));
     std::vector<void*> owned;
     auto alloc = [&](void** p, size_t bytes) -> hipError_t { hipError_t e = hipMalloc(p, bytes ? bytes : 8); if (e == hipSuccess) owned.push_back(*p); return e; };
     auto release = [&]() { for (void* p : owned) (void)hipFree(p); };
@@ -2008,7 +2142,7 @@ static int topk_impl(const DevModel& m0, const int32_t* users_host, int n_users,
         hipLaunchKernelGGL(build_queries_kernel<T>, dim3(blocks_for_waves(ev.nq)), dim3(256), 0, st, m, ev);
         int rc = 0;
         if (l1) {
-            rc = launch_score_l1<T, true>(ev, (const T*)m.tab[TR_H], qtest, qval, I, m.K, st);
+            rc = launch_score_l1<T, 1>(ev, (const T*)m.tab[TR_H], qtest, qval, I, m.K, st);
         } else {
             rc = launch_score<T, false, true>(ev, ev.seg0 >= 0 ? (const T*)m.tab[ev.seg0] : nullptr, ev.seg1 >= 0 ? (const T*)m.tab[ev.seg1] : nullptr, I, qtest, qval, st);
         }
@@ -2620,6 +2754,128 @@ static int topk_fused_impl(const DevModel& m0, const int32_t* users_host, int n_
     return 0;
 }
 
+// One wavefront per query of the |.|_1 sweep: clicked items out of what the list still holds, the context's positive in
+// with the score the reference formula gives it, ordered by (score descending, item id ascending).
+__global__ void __launch_bounds__(256) topk_l1_finish_kernel(DevModel m, EvalDev ev, TopkL1Dev tk)
+{
+    __shared__ int s_item[4][L1_LIST + 1];
+    __shared__ double s_score[4][L1_LIST + 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int w = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (w >= ev.nq) return;
+    const int k = tk.k;
+    int32_t* items = tk.items_out + (int64_t)w * k;
+    double* scores = tk.scores_out + (int64_t)w * k;
+    if (tk.q_over[w]) {                        // left to the caller's fallback
+        for (int r = lane; r < k; r += 64) { items[r] = -1; scores[r] = -INFINITY; }
+        return;
+    }
+    const int4 meta = tk.qmeta[w];
+    const int32_t* clk = m.clk_item + m.clk_off[meta.x]; const int nc = (int)(m.clk_off[meta.x + 1] - m.clk_off[meta.x]);
+    const double* cs = tk.cand_s + (int64_t)w * L1_LIST; const int32_t* ci = tk.cand_i + (int64_t)w * L1_LIST;
+    const int n = tk.cand_cnt[w];
+    int ns = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int idx = i0 + lane;
+        const int item = idx < n ? ci[idx] : -1;
+        const double sc = idx < n ? cs[idx] : 0.0;
+        const bool keep = idx < n && !sorted_contains(clk, nc, item);
+        const unsigned long long bal = __ballot(keep);
+        if (keep) { const int at = ns + __popcll(bal & ((1ull << lane) - 1ull)); s_item[wv][at] = item; s_score[wv][at] = sc; }
+        ns += __popcll(bal);
+    }
+    if (lane == 0) { s_item[wv][ns] = meta.y; s_score[wv][ns] = ev.thr[w]; }
+    const int nt = ns + 1;
+    const double aq = ev.aq[w];
+    __builtin_amdgcn_wave_barrier();
+    // LDS writes of this wavefront are visible to its later reads (in order); rank by counting
+    for (int i = lane; i < nt; i += 64) {
+        const double si = s_score[wv][i]; const int ii = s_item[wv][i];
+        int rank = 0;
+        for (int x = 0; x < nt; x++) { const double sx = s_score[wv][x]; rank += (sx > si || (sx == si && s_item[wv][x] < ii)) ? 1 : 0; }
+        if (rank < k) { items[rank] = ii; scores[rank] = si + aq; }
+    }
+    for (int r = nt + lane; r < k; r += 64) { items[r] = -1; scores[r] = -INFINITY; }
+}
+
+// users_host == nullptr: the first n_users users of m.eval_users.  fallback: positions (in users order) whose lists held
+// too many ties; *all_fallback: this shape is not served (K above 160).
+template <class T>
+static int topk_l1_impl(const DevModel& m0, const int32_t* users_host, int n_users, int k, int32_t* items_host, double* scores_host,
+                        hipStream_t st, std::vector<int32_t>& fallback, bool* all_fallback)
+{
+    DevModel m = m0;
+    const int I = m.I;
+    *all_fallback = false;
+    if (m.K > 160) { *all_fallback = true; return 0; }
+    EvalDev ev = {};
+    ev.nctx = 2; ev.force2 = 1;
+    ev.seg0 = TR_H; ev.seg1 = -1; ev.K1 = m.K; ev.K2 = 0;
+    ev.KQ = m.K <= 16 ? 16 : m.K <= 32 ? 32 : m.K <= 64 ? 64 : m.K <= 128 ? 128 : 256;
+    constexpr int QT = 32;
+    const int batch_users = std::min(n_users, 1 << 17);
+    const int max_rows = ((2 * batch_users + QT - 1) / QT) * QT;
+    std::vector<void*> owned;
+    auto alloc = [&](void** p, size_t bytes) -> hipError_t { hipError_t e = hipMalloc(p, bytes ? bytes : 8); if (e == hipSuccess) owned.push_back(*p); return e; };
+    auto release = [&]() { for (void* p : owned) (void)hipFree(p); };
+#define TL_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { rec_set_error(std::string(#expr) + ": " + hipGetErrorString(_e)); release(); return -2; } } while (0)
+    TopkL1Dev tk = {};
+    tk.k = k; tk.clk_off = m.clk_off; tk.clk_item = m.clk_item;
+    int32_t* d_users = nullptr; int4* qmeta = nullptr;
+    if (users_host) TL_TRY(alloc((void**)&d_users, sizeof(int32_t) * batch_users));
+    TL_TRY(alloc((void**)&ev.Q, sizeof(double) * (size_t)max_rows * ev.KQ));
+    TL_TRY(alloc((void**)&ev.thr, sizeof(double) * max_rows));
+    TL_TRY(alloc((void**)&ev.thr2, sizeof(double) * max_rows));
+    TL_TRY(alloc((void**)&ev.aq, sizeof(double) * max_rows));
+    TL_TRY(alloc((void**)&ev.bconst, sizeof(double) * I));
+    TL_TRY(alloc((void**)&ev.xpos, sizeof(double) * (size_t)m.U * 2));
+    TL_TRY(alloc((void**)&qmeta, sizeof(int4) * max_rows));
+    TL_TRY(alloc((void**)&tk.cand_s, sizeof(double) * (size_t)max_rows * L1_LIST));
+    TL_TRY(alloc((void**)&tk.cand_i, sizeof(int32_t) * (size_t)max_rows * L1_LIST));
+    TL_TRY(alloc((void**)&tk.cand_cnt, sizeof(int32_t) * max_rows));
+    TL_TRY(alloc((void**)&tk.q_over, sizeof(int32_t) * max_rows));
+    TL_TRY(alloc((void**)&tk.items_out, sizeof(int32_t) * (size_t)batch_users * 2 * k));
+    TL_TRY(alloc((void**)&tk.scores_out, sizeof(double) * (size_t)batch_users * 2 * k));
+    tk.qmeta = qmeta;
+    ev.col_b = ev.bconst; ev.n_cols = I;
+    hipLaunchKernelGGL(item_consts_kernel<T>, dim3(blocks_for_waves(I)), dim3(256), 0, st, m, ev);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    TL_TRY(hipEventCreate(&e0)); TL_TRY(hipEventCreate(&e1));
+    std::vector<int32_t> over_host;
+    g_topk_fused_lists = 0; g_topk_fused_ms = 0;
+    const int32_t* all_users = m0.eval_users;
+    for (int u0 = 0; u0 < n_users; u0 += batch_users) {
+        const int nu = std::min(batch_users, n_users - u0);
+        if (users_host) { TL_TRY(hipMemcpyAsync(d_users, users_host + u0, sizeof(int32_t) * nu, hipMemcpyHostToDevice, st)); m.eval_users = d_users; }
+        else m.eval_users = all_users + u0;
+        m.n_eval = nu;
+        ev.nq = 2 * nu; ev.nq_pad = ((ev.nq + QT - 1) / QT) * QT;
+        TL_TRY(hipEventRecord(e0, st));
+        TL_TRY(hipMemsetAsync(ev.Q, 0, sizeof(double) * (size_t)ev.nq_pad * ev.KQ, st));
+        TL_TRY(hipMemsetAsync(tk.q_over, 0, sizeof(int32_t) * ev.nq_pad, st));
+        hipLaunchKernelGGL(topk_meta_kernel, dim3((ev.nq_pad + 255) / 256), dim3(256), 0, st, m, ev, qmeta);
+        hipLaunchKernelGGL(build_queries_kernel<T>, dim3(blocks_for_waves(ev.nq)), dim3(256), 0, st, m, ev);
+        if (int rc = launch_score_l1<T, 2>(ev, (const T*)m.tab[TR_H], nullptr, nullptr, I, m.K, st, tk)) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); release(); return rc; }
+        hipLaunchKernelGGL(topk_l1_finish_kernel, dim3(blocks_for_waves(ev.nq)), dim3(256), 0, st, m, ev, tk);
+        TL_TRY(hipGetLastError());
+        TL_TRY(hipEventRecord(e1, st));
+        over_host.resize(ev.nq);
+        TL_TRY(hipMemcpyAsync(over_host.data(), tk.q_over, sizeof(int32_t) * ev.nq, hipMemcpyDeviceToHost, st));
+        TL_TRY(hipMemcpyAsync(items_host + (size_t)u0 * 2 * k, tk.items_out, sizeof(int32_t) * (size_t)nu * 2 * k, hipMemcpyDeviceToHost, st));
+        if (scores_host) TL_TRY(hipMemcpyAsync(scores_host + (size_t)u0 * 2 * k, tk.scores_out, sizeof(double) * (size_t)nu * 2 * k, hipMemcpyDeviceToHost, st));
+        TL_TRY(hipStreamSynchronize(st));
+        float ms = 0; TL_TRY(hipEventElapsedTime(&ms, e0, e1)); g_topk_fused_ms += ms;
+        for (int a = 0; a < nu; a++) {
+            if (over_host[2 * a] || over_host[2 * a + 1]) fallback.push_back(u0 + a);
+            else g_topk_fused_lists += 2;
+        }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    release();
+#undef TL_TRY
+    return 0;
+}
+
 int eval_topk(const DevModel& m, int precision, const int32_t* users_host, int n_users, int k, int32_t* items_host,
               double* scores_host, hipStream_t st)
 {
@@ -2629,11 +2885,17 @@ int eval_topk(const DevModel& m, int precision, const int32_t* users_host, int n
     if (!users_host && (n_users < 0 || n_users > m.n_eval)) { rec_set_error("more users than have a test item"); return -1; }
     const bool fused = g_topk_fused && precision == REC_F32 && k <= 64 && m.K + m.KK > 0 && m.I < (1 << 28) &&
                        m.model != REC_MP && m.model != REC_TRANSREC_L1;
-    std::vector<int32_t> fallback; bool all_fallback = !fused;
+    // TransRec_L1: the lists come out of the |.|_1 sweep (fp64 scores, either table precision)
+    const bool l1_lists = g_topk_fused && k <= 64 && m.model == REC_TRANSREC_L1;
+    std::vector<int32_t> fallback; bool all_fallback = !fused && !l1_lists;
     if (fused) { if (int rc = topk_fused_impl(m, users_host, n_users, k, items_host, scores_host, st, fallback, &all_fallback)) return rc; }
+    if (l1_lists) {
+        if (int rc = precision == REC_F64 ? topk_l1_impl<double>(m, users_host, n_users, k, items_host, scores_host, st, fallback, &all_fallback)
+                                          : topk_l1_impl<float>(m, users_host, n_users, k, items_host, scores_host, st, fallback, &all_fallback)) return rc;
+    }
     if (!all_fallback && fallback.empty()) return 0;
-    // the score-matrix path: everything (f64 tables, k > 64, TransRec_L1, MostPopular, operands out of the f16 sweep's
-    // range) or the users whose lists the fused path gave up on
+    // the score-matrix path: everything (f64 tables, k > 64, MostPopular, operands out of the f16 sweep's range) or the
+    // users whose lists the fused path gave up on
     if (!users_host) {
         all.resize(n_users);
         HIP_TRY(hipMemcpy(all.data(), m.eval_users, sizeof(int32_t) * n_users, hipMemcpyDeviceToHost));
@@ -2647,7 +2909,8 @@ int eval_topk(const DevModel& m, int precision, const int32_t* users_host, int n
     }
     std::vector<int32_t> fu(fallback.size()), fi(fallback.size() * 2 * k); std::vector<double> fs(fallback.size() * 2 * k);
     for (size_t a = 0; a < fallback.size(); a++) fu[a] = users_host[fallback[a]];
-    if (int rc = topk_impl<float>(m, fu.data(), (int)fu.size(), k, fi.data(), fs.data(), st)) return rc;
+    if (int rc = precision == REC_F64 ? topk_impl<double>(m, fu.data(), (int)fu.size(), k, fi.data(), fs.data(), st)
+                                      : topk_impl<float>(m, fu.data(), (int)fu.size(), k, fi.data(), fs.data(), st)) return rc;
     for (size_t a = 0; a < fallback.size(); a++) {
         memcpy(items_host + (size_t)fallback[a] * 2 * k, fi.data() + a * 2 * k, sizeof(int32_t) * 2 * k);
         if (scores_host) memcpy(scores_host + (size_t)fallback[a] * 2 * k, fs.data() + a * 2 * k, sizeof(double) * 2 * k);

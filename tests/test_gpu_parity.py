@@ -209,10 +209,59 @@ def test_fused_topk_toy_all_models(model):
     for k in (1, 7, 50, 64):
         items, scores = e.eval_topk(users, k)
         fused = e.kernel_stats(5)[1]
-        assert fused == (0 if model == "TransRec_L1" else 2 * len(users)), (model, k, fused)   # |.|_1 is not a contraction
+        assert fused == 2 * len(users), (model, k, fused)   # TransRec_L1 too: its lists come out of the |.|_1 sweep
         for a, u in enumerate(users):
             for ctx in (0, 1):
                 _check_topk(o.score_row(W, int(u), ctx), items[a, ctx], scores[a, ctx], k)
+    e.close()
+
+
+@pytest.mark.parametrize("prec", [F32, F64])
+def test_l1_top50_out_of_the_sweep_match_oracle_and_score_matrix(prec):
+    """TransRec_L1 on the ML-5 corpus (parameters: the reference-saved TransRec model, scored with |.|_1): the lists of
+    every user come out of the |.|_1 sweep itself, equal the oracle's modulo ties and the score-matrix path's, and HIT@50
+    of model.cpp:52-58 is membership of the positive."""
+    g, model, co, ci, labels = fixture_case("TransRec", "ml5")
+    W = g["W_micro"].astype(np.float64) / 1e6
+    if prec == F32:
+        W = _f32(W)
+    e = make_engine(g, "TransRec_L1", co, ci, labels, prec)
+    e.upload(W)
+    o = make_oracle(g, "TransRec_L1", co, ci, labels)
+    valid = np.nonzero(np.asarray(g["counts"])[:, 2] >= 0)[0].astype(np.int32)
+    items, scores = e.eval_topk(len(valid), 50)
+    assert e.kernel_stats(5)[1] == 2 * len(valid)
+    _, counts, _ = e.eval()
+    rank = counts[valid, 2:3] - counts[valid, 0:2]
+    pos = np.stack([o.val_item[valid], o.test_item[valid]], 1)
+    assert np.array_equal((items == pos[:, :, None]).any(2), rank < 50)
+    exact = 0
+    picked = valid[:: max(1, len(valid) // 96)][:96]
+    for u in picked:
+        a = int(np.searchsorted(valid, u))
+        for ctx in (0, 1):
+            exact += _check_topk(o.score_row(W, int(u), ctx), items[a, ctx], scores[a, ctx], 50)
+    assert exact >= 0.9 * 2 * len(picked)
+    sub = valid[3:900:5]
+    i2, s2 = e.eval_topk(sub, 50)
+    assert np.array_equal(i2, items[3:900:5]) and np.array_equal(s2, scores[3:900:5])
+    e.set_option("topk_fused", 0)
+    try:
+        i3, s3 = e.eval_topk(sub, 50)
+        assert e.kernel_stats(5)[1] == 0
+    finally:
+        e.set_option("topk_fused", 1)
+    assert np.allclose(s3, s2, rtol=1e-12, atol=1e-12)
+    assert (i3 == i2).mean() > 0.99
+    # all-zero tables: every candidate ties, no list can hold them, the score-matrix path answers (lowest item ids first)
+    Z = np.zeros(e.nw)
+    e.upload(Z)
+    users = valid[:48]
+    items, scores = e.eval_topk(users, 50)
+    assert e.kernel_stats(5)[1] == 0
+    for a, u in enumerate(users):
+        for ctx in (0, 1):
+            assert _check_topk(o.score_row(Z, int(u), ctx), items[a, ctx], scores[a, ctx], 50)
     e.close()
 
 

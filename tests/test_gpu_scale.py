@@ -179,6 +179,53 @@ def test_full_shape_other_models_replay_and_counts(corpus, model):
     eng.close()
 
 
+def test_full_shape_l1_top50_lists_out_of_the_sweep(corpus):
+    """TransRec_L1 on the 1M x 200k x 100M corpus after a stretch of training: the top-50 lists of a 64k-user shard come
+    out of the |.|_1 sweep itself (no score matrix), the positive is a member exactly when fewer than 50 candidates are
+    counted at or above it (HIT@50, model.cpp:52-58), sampled users' lists equal the restated ranking modulo ties, and the
+    score-matrix path gives the same lists."""
+    import recommendation_amd as ra
+    from oracle import oracle_py as orc
+    from recommendation_amd.capi import F32
+    from tests.test_gpu_parity import _check_topk
+    seq_off, seq_item, test, val = corpus
+    kw = dict(K=K, L=1, lam=0.01, bias_reg=0.01, relation_reg=0.01, alpha=0.0)
+    ub, ue = 100_000, 165_536
+    eng = ra.Engine("TransRec_L1", I, seq_off, seq_item, test, val, precision=F32, user_begin=ub, user_end=ue, **kw)
+    eng.init_params(seed=5)
+    eng.sgd_epoch(0.05, eng.steps_per_epoch, seed=5, epoch=0)
+    eng.sync()
+    W1 = eng.download()
+    assert np.isfinite(W1).all()
+    m, counts, _ = eng.eval()
+    n_all = int(m.n_users)
+    assert n_all == ue - ub
+    items, scores = eng.eval_topk(n_all, 50)
+    assert eng.kernel_stats(5)[1] == 2 * n_all
+    mine = np.arange(ub, ue)
+    pos = np.stack([val[mine], test[mine]], 1)
+    member = (items == pos[:, :, None]).any(2)
+    rank = counts[mine, 2:3] - counts[mine, 0:2]
+    assert np.array_equal(member, rank < 50)
+    assert (np.diff(scores, axis=2) <= 0).all() and (items >= 0).all()
+    users = np.linspace(ub, ue - 1, 16).astype(np.int64)
+    t_s = np.full(U, -1, np.int32); t_s[users] = test[users]
+    o = orc.Oracle("TransRec_L1", U, I, K, seq_off, seq_item, t_s, val, **{k: v for k, v in kw.items() if k != "K"})
+    for u in users:
+        for ctx in (0, 1):
+            _check_topk(o.score_row(W1, int(u), ctx), items[u - ub, ctx], scores[u - ub, ctx], 50)
+    few = np.linspace(ub, ue - 1, 96).astype(np.int32)
+    eng.set_option("topk_fused", 0)
+    try:
+        i3, s3 = eng.eval_topk(few, 50)
+        assert eng.kernel_stats(5)[1] == 0
+    finally:
+        eng.set_option("topk_fused", 1)
+    assert np.allclose(s3, scores[few - ub], rtol=1e-12, atol=1e-12)
+    assert (i3 == items[few - ub]).mean() > 0.99
+    eng.close()
+
+
 def test_full_shape_rebus_mincount2_L10(corpus):
     """REBUS with the label set mined at minCount 2 / L 10 on the 1M x 200k x 100M corpus (the setting of the fourth
     benchmark configuration): labels mined and paths matched by the library (REBUS.cpp:3-87, 484-524), a sample of
