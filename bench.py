@@ -532,13 +532,23 @@ def main():
         # MFMAs per contraction step, so it executes 3x the algorithmic flops.  `achieved` is algorithmic (2 C K' I per
         # user) against the dense f16 peak; `executed` counts the MFMAs that ran.
         peak = F16_MFMA_PEAK_TFLOPS if screened else FP64_MFMA_PEAK_TFLOPS
+        l1 = args.model == "TransRec_L1"
         out["eval"] = {"users_per_sec": round(n_eval / et, 1), "seconds": round(et, 4), "calls": ecalls, "users": int(n_eval),
                        "auc_test": round(float(sums[1] / n_eval), 6), "hit50_test": round(float(sums[3] / n_eval), 6),
-                       "roofline": {"bound": "mfma", "kernel": "score_screen16_kernel" if screened else "score_count_l1_kernel" if args.model == "TransRec_L1" else "score_count_kernel",
+                       "roofline": {"bound": "mfma", "kernel": "score_screen16_kernel" if screened else "score_count_kernel",
                                     "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
                                     "dtype": "f16 halves of f32 operands (three MFMAs per step), proven rounding margin, undecided columns in f64" if screened else "f64",
                                     "launch_ms": round(sc_ms, 3)}}
-        if screened:
+        if l1:
+            # |.|_1 is no contraction: the sweep runs on the vector ALU, two operations (|a - b|, +) per term - one v_sad_u32 on
+            # fixed-point operands when the integer screen holds, two fp64 additions otherwise - against the vector peak
+            # (256 CUs x 4 SIMDs x 16 lanes x 2 operations x 2.4 GHz; the same for 32-bit integers and fp64)
+            out["eval"]["roofline"].update({"bound": "valu", "kernel": "score_count_l1_sad_kernel" if screened else "score_count_l1_kernel",
+                                            "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "Top/s", "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4),
+                                            "dtype": "u32 fixed point (one v_sad_u32 per term), proven quantisation margin, undecided columns in f64" if screened else "f64"})
+            if screened:
+                out["eval"]["roofline"]["undecided_columns_per_query"] = round(open_cols / max(1.0, n_eval * nctx), 2)
+        elif screened:
             out["eval"]["roofline"]["executed"] = round(3 * tf, 2)
             out["eval"]["roofline"]["executed_frac"] = round(3 * tf / peak, 4)
             out["eval"]["roofline"]["undecided_columns_per_query"] = round(open_cols / max(1.0, n_eval * nctx), 2)

@@ -291,6 +291,9 @@ int rec_project_rows(rec_engine* e);
  *                   fp64, so the counts are those of the fp64 sweep.  1 (default): the 16-bit pipe, every operand as two f16
  *                   halves under power-of-two scales (three MFMAs per 32 contraction indices); 2: the FP32 matrix pipe; 0: the
  *                   fp64 sweep.  Tables or queries that are not finite always take the fp64 sweep.  (process-wide)
+ *                   TransRec_L1 (either table precision; 1 or 2): its |.|_1 sweep runs on fixed-point operands, one v_sad_u32
+ *                   per term, within a proven quantisation bound; lists of 64 undecided columns per query, and the whole
+ *                   sweep in fp64 if one overflows.
  *   "eval_screen_cap"  columns per query the screen may leave to fp64 (default 0 = n_items / 512 within 128 .. 1024, f32 screen:
  *                   max(64, n_items / 2048)); queries that need more are swept again in fp64 - on their own when they are
  *                   few (at most 1/8 of the queries), else the whole sweep moves to the next narrower margin

@@ -146,12 +146,22 @@ __global__ void __launch_bounds__(256) build_queries_kernel(DevModel m, EvalDev 
         break;
     }
     case REC_TRANSREC_L1: {  // TransRec_L1.cpp:85-92; scored by the |.|_1 kernel, so q is kept unscaled
-        double d = 0;
-        for (int k = lane; k < K; k += 64) {
-            const double g = B.ld(TR_H, prev, K, k) + B.sc(TR_r, k) + B.ld(TR_R, u, K, k);
-            q[k] = g; d += fabs(g - B.ld(TR_H, pos, K, k));
+        // The positive's score is summed exactly as the reference sums it (from beta, k ascending), and so is every score
+        // it is compared with (l1_seq_score, score_count_l1_kernel): sums of |differences| of parameters read from a
+        // six-decimal model file are multiples of 1e-6 and TIE with the positive's a few times per thousand queries, and a
+        // tie must compare equal, as it does in the reference, not by the last bit of two summation orders.
+        double pred = B.sc(TR_BETA, pos);
+        for (int k0 = 0; k0 < K; k0 += 64) {
+            const int k = k0 + lane;
+            double term = 0;
+            if (k < K) {
+                const double g = B.ld(TR_H, prev, K, k) + B.sc(TR_r, k) + B.ld(TR_R, u, K, k);
+                q[k] = g; term = fabs(g - B.ld(TR_H, pos, K, k));
+            }
+            const int n = min(64, K - k0);
+            for (int l = 0; l < n; l++) pred += __shfl(term, l, 64);
         }
-        xa = -(B.sc(TR_BETA, pos) + B.wsum(d));
+        xa = -pred;
         break;
     }
     case REC_FOSSIL_SIMPLE: case REC_FOSSIL: {
@@ -1256,9 +1266,11 @@ __global__ void __launch_bounds__(256) score_count_l1_kernel(EvalDev ev, const T
         __syncthreads();
         if (ahead && item0 + TI < I) request(item0 + TI);
         const int j = item0 + jj;
+        // a score is summed as the reference sums it (TransRec_L1.cpp:87-91): from b_j, k ascending
+        const double bj0 = j < I ? ev.col_b[j] : 0.0;
         double acc[QPT];
 #pragma unroll
-        for (int a = 0; a < QPT; a++) acc[a] = 0;
+        for (int a = 0; a < QPT; a++) acc[a] = bj0;
         if constexpr (TI == 64) {
             // a wavefront is one query group: its QPT queries are the same on every lane.  Read from the query array with a
             // wave-uniform address they arrive in scalar registers (scalar loads, four components at a time) instead of
@@ -1293,12 +1305,11 @@ __global__ void __launch_bounds__(256) score_count_l1_kernel(EvalDev ev, const T
         }
         if constexpr (MODE == 2) {
             const bool inr = j < I;
-            const double bj = inr ? ev.col_b[j] : 0.0;
             const int jid = inr ? (ev.col_item ? ev.col_item[j] : j) : -1;
             bool crowded = false;
 #pragma unroll
             for (int a = 0; a < QPT; a++) {
-                const double sc = -(bj + acc[a]) + 0.0;       // (+ 0.0: one zero, so that keys order exactly like the scores)
+                const double sc = -acc[a] + 0.0;              // (+ 0.0: one zero, so that keys order exactly like the scores)
                 const bool in = inr && jid != ex1[a] && jid != ex2[a] && sc >= thr[a];
                 const unsigned long long bal = __ballot(in);
                 if (bal) {
@@ -1336,12 +1347,11 @@ __global__ void __launch_bounds__(256) score_count_l1_kernel(EvalDev ev, const T
                 for (int a = 0; a < QPT; a++) { cnt[a] = (int)sw[2 * a]; thr[a] = sw[2 * a + 1]; }
             }
         } else if (j < I) {
-            const double bj = ev.col_b[j];
             const int jid = ev.col_item ? ev.col_item[j] : j;
 #pragma unroll
             for (int a = 0; a < QPT; a++) {
-                if (STORE) ev.S[(qbase + qg + NG * a) * (int64_t)I + j] = -(bj + acc[a]);
-                else cnt[a] += (jid != ex1[a] && jid != ex2[a] && thr[a] > -(bj + acc[a])) ? 1 : 0;
+                if (STORE) ev.S[(qbase + qg + NG * a) * (int64_t)I + j] = -acc[a];
+                else cnt[a] += (jid != ex1[a] && jid != ex2[a] && thr[a] > -acc[a]) ? 1 : 0;
             }
         }
     }
@@ -1377,6 +1387,164 @@ static int launch_score_l1(const EvalDev& ev, const T* H, const int32_t* qtest, 
     }
     if (hipGetLastError() != hipSuccess) { rec_set_error("launch of the L1 scoring kernel failed"); return -2; }
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Integer screen of the |.|_1 sweep.  sum_k |q_k - t_k| is no contraction, but on fixed-point operands it is one vector
+// instruction per term: v_sad_u32 (D = |a - b| + c, exact).  Tables and queries are mapped to unsigned integers,
+//     x' = rint((x + A) / delta),   A = max |x| over both,   delta = 2 A / (R - 1),   R = floor((2^32 - 1) / K),
+// so that every sum of K differences fits 32 bits.  Each operand is off by at most delta / 2 (+ the double rounding of the
+// mapping), a difference by at most delta, the sum S' by at most K delta:  | sum_k |q_k - t_k| - delta S' | <= 1.0002 K delta.
+// In units of delta, with B_j = b_j / delta and T_q = threshold / delta, y = S' + B_j + T_q decides
+//     y >  M : the column counts (threshold > -(b_j + sum)),    y < -M : it does not,     M = 1.0002 K + 2,
+// and what lies between (or is not a number) goes to the query's list of undecided columns, which correct_clicked_kernel decides in fp64 - the
+// held-out pair included (its own column is undecided by construction and cancels there against the pair's entry).
+// Half the vector instructions of the fp64 sweep and half its LDS and scalar-load bytes; the counts are identical.
+__global__ void __launch_bounds__(256) l1_absmax_kernel(const void* __restrict__ H, int is_f64, int64_t nH, const double* __restrict__ Q, int64_t nQ,
+                                                        unsigned* __restrict__ bound)
+{
+    float mx = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = t0; i < nH; i += stride) {
+        const double x = is_f64 ? ((const double*)H)[i] : (double)((const float*)H)[i];
+        const float a = __double2float_ru(fabs(x));
+        mx = (a > mx || a != a) ? a : mx;             // a NaN stays
+    }
+    for (int64_t i = t0; i < nQ; i += stride) {
+        const float a = __double2float_ru(fabs(Q[i]));
+        mx = (a > mx || a != a) ? a : mx;
+    }
+    // (bit patterns of non-negative floats order like the floats; NaN patterns are above infinity's)
+    unsigned b = __float_as_uint(mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(bound, b);
+}
+
+__device__ __forceinline__ void l1_scale(const unsigned* bound, int K, double& A, double& inv_delta, bool& ok)
+{
+    const float a = __uint_as_float(bound[0]);
+    ok = a == a && a < 3.0e38f;
+    A = ok ? fmax((double)a, 1e-30) : 1.0;       // (all-zero operands: any scale does, and this one keeps 1 / delta finite)
+    const double R = floor(4294967295.0 / (double)K);
+    inv_delta = (R - 1.0) / (2.0 * A);
+}
+
+__global__ void __launch_bounds__(256) l1_quant_items_kernel(const void* __restrict__ H, int is_f64, int I, int K, const double* __restrict__ b,
+                                                             const unsigned* __restrict__ bound, uint32_t* __restrict__ Hi, double* __restrict__ Bj,
+                                                             int32_t* __restrict__ flags)
+{
+    double A, inv; bool ok; l1_scale(bound, K, A, inv, ok);
+    const int64_t n = (int64_t)I * K, stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (!ok) { if (t0 == 0) flags[1] = 1; return; }
+    for (int64_t i = t0; i < n; i += stride) {
+        const double x = is_f64 ? ((const double*)H)[i] : (double)((const float*)H)[i];
+        Hi[i] = (uint32_t)rint((x + A) * inv);
+    }
+    for (int64_t j = t0; j < I; j += stride) Bj[j] = b[j] * inv;
+}
+
+__global__ void __launch_bounds__(256) l1_quant_queries_kernel(EvalDev ev, int K, const unsigned* __restrict__ bound, uint32_t* __restrict__ Qi,
+                                                               double* __restrict__ Tq)
+{
+    double A, inv; bool ok; l1_scale(bound, K, A, inv, ok);
+    if (!ok) return;
+    const int64_t n = (int64_t)ev.nq_pad * K, stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = t0; i < n; i += stride) {
+        const int64_t q = i / K; const int k = (int)(i % K);
+        Qi[i] = (uint32_t)rint((ev.Q[q * ev.KQ + k] + A) * inv);
+    }
+    for (int64_t q = t0; q < ev.nq_pad; q += stride) Tq[q] = ev.thr[q] * inv;
+}
+
+// a block owns QT queries for the whole catalog (tiles of 64 items through LDS, the next tile requested while the current
+// one is scored); a wavefront is 64 items against QT / 4 queries, which arrive through scalar loads
+template <int QT>
+__global__ void __launch_bounds__(256) score_count_l1_sad_kernel(EvalDev ev, const uint32_t* __restrict__ Hi, const uint32_t* __restrict__ Qi,
+                                                                 const double* __restrict__ Bj, const double* __restrict__ Tq, int I, int K, double M)
+{
+    constexpr int TI = 64, NG = 4, QPT = QT / NG, PF = 16;
+    extern __shared__ uint32_t tile_u[];          // [TI][STR]
+    const int STR = K | 1;
+    const int tid = threadIdx.x, jj = tid & 63, qg = tid >> 6;
+    const int64_t qbase = (int64_t)blockIdx.x * QT;
+    double tq[QPT]; int cnt[QPT], open[QPT];
+#pragma unroll
+    for (int a = 0; a < QPT; a++) { tq[a] = Tq[qbase + qg + NG * a]; cnt[a] = 0; open[a] = 0; }
+    uint32_t pre[PF]; int lofs[PF];
+#pragma unroll
+    for (int e = 0; e < PF; e++) { const int i = tid + 256 * e; lofs[e] = i < TI * K ? (i / K) * STR + i % K : -1; pre[e] = 0; }
+    const int64_t end = (int64_t)I * K;
+    auto request = [&](int item0) {
+        const int64_t base = (int64_t)item0 * K;
+#pragma unroll
+        for (int e = 0; e < PF; e++) { const int64_t g = base + tid + 256 * e; pre[e] = (lofs[e] >= 0 && g < end) ? Hi[g] : 0u; }
+    };
+    const bool ahead = TI * K <= 256 * PF;        // wider tiles are staged when they are needed
+    if (ahead) request(0);
+    const int qgu = __builtin_amdgcn_readfirstlane(qg);
+    typedef const __attribute__((address_space(4))) uint32_t* const_u32_ptr;
+    const_u32_ptr qrow = (const_u32_ptr)(uintptr_t)(Qi + (qbase + qgu) * K);
+    const int64_t qstep = (int64_t)NG * K;
+    for (int item0 = 0; item0 < I; item0 += TI) {
+        __syncthreads();
+        if (ahead) {
+#pragma unroll
+            for (int e = 0; e < PF; e++) if (lofs[e] >= 0) tile_u[lofs[e]] = pre[e];
+        } else {
+            const int64_t base = (int64_t)item0 * K;
+            for (int i = tid; i < TI * K; i += 256) tile_u[(i / K) * STR + i % K] = base + i < end ? Hi[base + i] : 0u;
+        }
+        __syncthreads();
+        if (ahead && item0 + TI < I) request(item0 + TI);
+        const int j = item0 + jj;
+        uint32_t acc[QPT];
+#pragma unroll
+        for (int a = 0; a < QPT; a++) acc[a] = 0;
+        const uint32_t* trow = tile_u + jj * STR;
+        int k = 0;
+        // (four terms per round: with eight the queries of a round no longer fit the scalar registers, 1.41 -> 2.48 s per 2M queries)
+        for (; k + 4 <= K; k += 4) {
+            const uint32_t t0 = trow[k], t1 = trow[k + 1], t2 = trow[k + 2], t3 = trow[k + 3];
+#pragma unroll
+            for (int a = 0; a < QPT; a++) {
+                const_u32_ptr qa = qrow + a * qstep + k;
+                acc[a] = __usad(t0, qa[0], acc[a]); acc[a] = __usad(t1, qa[1], acc[a]);
+                acc[a] = __usad(t2, qa[2], acc[a]); acc[a] = __usad(t3, qa[3], acc[a]);
+            }
+        }
+        for (; k < K; k++) {
+            const uint32_t t = trow[k];
+#pragma unroll
+            for (int a = 0; a < QPT; a++) acc[a] = __usad(t, qrow[a * qstep + k], acc[a]);
+        }
+        const bool inr = j < I;
+        const double bj = inr ? Bj[j] : 0.0;
+#pragma unroll
+        for (int a = 0; a < QPT; a++) {
+            const double y = (double)acc[a] + bj + tq[a];
+            const bool yes = inr && y > M;
+            const bool und = inr && !(y > M) && !(y < -M);      // (a y that is not a number is left to fp64 as well)
+            cnt[a] += yes ? 1 : 0;
+            const unsigned long long bal = __ballot(und);
+            if (bal) {
+                const int at = open[a] + __popcll(bal & ((1ull << jj) - 1ull));
+                if (und && at < ev.amb_cap) ev.amb[(qbase + qg + NG * a) * (int64_t)ev.amb_cap + at] = j | (1 << 28);
+                open[a] += __popcll(bal);
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < QPT; a++) {
+        int c = cnt[a];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if (jj == 0) {
+            ev.cnt[qbase + qg + NG * a] = c;
+            ev.amb_cnt[qbase + qg + NG * a] = open[a];
+            if (open[a] > ev.amb_cap) *ev.amb_overflow = 1;
+        }
+    }
 }
 
 // Removes the clicked items from the counts, decides the columns the f32 screen left open, and writes (count_val,
@@ -1452,10 +1620,19 @@ __global__ void __launch_bounds__(256) correct_clicked_kernel(DevModel m, EvalDe
             acc[sb] = 0;
         }
         if (l1) {
-            for (int k = l16; k < K1; k += 16) {
-                const double qk = q[k];
+            // from b_j, k ascending (TransRec_L1.cpp:87-91): the 16 lanes of a group load 16 terms, every lane adds them in order
 #pragma unroll
-                for (int sb = 0; sb < 4; sb++) acc[sb] += fabs(qk - (double)seg0[ec[sb] * K1 + k]);
+            for (int sb = 0; sb < 4; sb++) acc[sb] = ev.bconst[ec[sb]];
+            for (int k0 = 0; k0 < K1; k0 += 16) {
+                const int k = k0 + l16;
+                const double qk = k < K1 ? q[k] : 0.0;
+                double t[4];
+#pragma unroll
+                for (int sb = 0; sb < 4; sb++) t[sb] = k < K1 ? fabs(qk - (double)seg0[ec[sb] * K1 + k]) : 0.0;
+                const int n = min(16, K1 - k0);
+                for (int l = 0; l < n; l++)
+#pragma unroll
+                    for (int sb = 0; sb < 4; sb++) acc[sb] += __shfl(t[sb], (lane & 48) + l, 64);
             }
         } else {
             for (int k = l16; k < K1; k += 16) {
@@ -1471,7 +1648,7 @@ __global__ void __launch_bounds__(256) correct_clicked_kernel(DevModel m, EvalDe
         }
 #pragma unroll
         for (int sb = 0; sb < 4; sb++) {
-            const double sc = l1 ? -(ev.bconst[ec[sb]] + group_sum<16>(acc[sb])) : group_sum<16>(acc[sb]) + ev.bconst[ec[sb]];
+            const double sc = l1 ? -acc[sb] : group_sum<16>(acc[sb]) + ev.bconst[ec[sb]];
             dc += ((whs[sb] & 1) && thr > sc) ? ws[sb] : 0;
             dc2 += ((whs[sb] & 2) && thr2 > sc) ? ws[sb] : 0;
         }
@@ -1537,9 +1714,16 @@ __global__ void __launch_bounds__(256) sample_count_kernel(DevModel m, EvalDev e
         const int64_t ec = j;
         double sv = 0, st = 0;
         if (l1) {
-            for (int k = l16; k < K1; k += 16) { const double t = (double)seg0[ec * K1 + k]; sv += fabs(qv[k] - t); if (two) st += fabs(qt[k] - t); }
-            const double b = ev.bconst[ec];
-            sv = -(b + group_sum<16>(sv)); st = two ? -(b + group_sum<16>(st)) : sv;
+            // from b_j, k ascending, as in correct_clicked_kernel
+            sv = st = ev.bconst[ec];
+            for (int k0 = 0; k0 < K1; k0 += 16) {
+                const int k = k0 + l16;
+                const double t = k < K1 ? (double)seg0[ec * K1 + k] : 0.0;
+                const double tv = k < K1 ? fabs(qv[k] - t) : 0.0, tt = (two && k < K1) ? fabs(qt[k] - t) : 0.0;
+                const int n = min(16, K1 - k0);
+                for (int l = 0; l < n; l++) { sv += __shfl(tv, (lane & 48) + l, 64); if (two) st += __shfl(tt, (lane & 48) + l, 64); }
+            }
+            sv = -sv; st = two ? -st : sv;
         } else {
             for (int k = l16; k < K1; k += 16) { const double t = (double)seg0[ec * K1 + k]; sv += qv[k] * t; if (two) st += qt[k] * t; }
             for (int k = l16; k < K2; k += 16) { const double t = (double)seg1[ec * K2 + k]; sv += qv[K1 + k] * t; if (two) st += qt[K1 + k] * t; }
@@ -1849,7 +2033,49 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
                             : launch_screen<false>(ev, (const float*)seg0_cols, (const float*)seg1_cols, NC, qtest, qval, st);
     };
     if (l1) {
-        rc = launch_score_l1<T, 0>(ev, seg0_cols, qtest, qval, NC, m.K, st);
+        // the integer screen (whole catalog, K <= 160: the 64-item tile, either table precision); "eval_screen" 0 or
+        // operands it cannot take (not finite), or a query with more undecided columns than its list holds: the fp64 sweep
+        bool held = false;
+        if (g_screen_on && n_subset <= 0 && m.K <= 160 && I < (1 << 28)) {
+            uint32_t *Hi = nullptr, *Qi = nullptr; double *Bj = nullptr, *Tq = nullptr; unsigned* bnd = nullptr;
+            ev.amb_cap = g_screen_cap > 0 ? g_screen_cap : 64;
+            EV_TRY(alloc((void**)&Hi, sizeof(uint32_t) * (size_t)I * m.K));
+            EV_TRY(alloc((void**)&Qi, sizeof(uint32_t) * (size_t)ev.nq_pad * m.K));
+            EV_TRY(alloc((void**)&Bj, sizeof(double) * (size_t)I));
+            EV_TRY(alloc((void**)&Tq, sizeof(double) * (size_t)ev.nq_pad));
+            EV_TRY(alloc((void**)&bnd, sizeof(unsigned)));
+            EV_TRY(alloc((void**)&ev.amb, sizeof(int32_t) * (size_t)ev.nq_pad * ev.amb_cap));
+            EV_TRY(alloc((void**)&ev.amb_cnt, sizeof(int32_t) * ev.nq_pad));
+            EV_TRY(alloc((void**)&ev.amb_overflow, sizeof(int32_t) * 2));
+            EV_TRY(hipMemsetAsync(ev.amb_overflow, 0, sizeof(int32_t) * 2, st));
+            EV_TRY(hipMemsetAsync(bnd, 0, sizeof(unsigned), st));
+            const int f64 = sizeof(T) == 8;
+            hipLaunchKernelGGL(l1_absmax_kernel, dim3(1024), dim3(256), 0, st, (const void*)seg0_cols, f64, (int64_t)I * m.K, (const double*)ev.Q,
+                               (int64_t)ev.nq_pad * ev.KQ, bnd);
+            hipLaunchKernelGGL(l1_quant_items_kernel, dim3(2048), dim3(256), 0, st, (const void*)seg0_cols, f64, I, m.K, (const double*)ev.col_b,
+                               (const unsigned*)bnd, Hi, Bj, ev.amb_overflow);
+            hipLaunchKernelGGL(l1_quant_queries_kernel, dim3(2048), dim3(256), 0, st, ev, m.K, (const unsigned*)bnd, Qi, Tq);
+            const size_t lds_bytes = sizeof(uint32_t) * (size_t)64 * (m.K | 1);
+            hipLaunchKernelGGL((score_count_l1_sad_kernel<L1_QT>), dim3((unsigned)(ev.nq_pad / L1_QT)), dim3(256), lds_bytes, st, ev, (const uint32_t*)Hi,
+                               (const uint32_t*)Qi, (const double*)Bj, (const double*)Tq, I, m.K, 1.0002 * m.K + 2.0);
+            EV_TRY(hipGetLastError());
+            int32_t over2[2] = {0, 0};
+            EV_TRY(hipMemcpyAsync(over2, ev.amb_overflow, sizeof over2, hipMemcpyDeviceToHost, st));
+            EV_TRY(hipStreamSynchronize(st));
+            held = !(over2[0] | over2[1]);
+            g_screen_mode = held ? 1 : 2; g_screen_open = 0;
+            if (held) {
+                ev.heldout_counted = 1;
+                if (profile) {
+                    std::vector<int32_t> open(ev.nq);
+                    EV_TRY(hipMemcpy(open.data(), ev.amb_cnt, sizeof(int32_t) * ev.nq, hipMemcpyDeviceToHost));
+                    for (int32_t x : open) g_screen_open += x > 0 ? x : 0;
+                }
+            } else {
+                ev.amb = nullptr; ev.heldout_counted = 0;
+            }
+        } else if (n_subset <= 0) { g_screen_mode = 0; g_screen_open = 0; }
+        if (!held) rc = launch_score_l1<T, 0>(ev, seg0_cols, qtest, qval, NC, m.K, st);
     } else if (screen16) {
         // operands as pairs of f16 halves under two power-of-two scales, margins, sweep on the 16-bit matrix pipe
         const int NI16 = KQ16 <= 128 ? 64 : 32;

@@ -231,7 +231,21 @@ def test_l1_top50_out_of_the_sweep_match_oracle_and_score_matrix(prec):
     valid = np.nonzero(np.asarray(g["counts"])[:, 2] >= 0)[0].astype(np.int32)
     items, scores = e.eval_topk(len(valid), 50)
     assert e.kernel_stats(5)[1] == 2 * len(valid)
+    # the counts behind AUC / HIT@50: the sweep on fixed-point operands (one v_sad_u32 per term, undecided columns in fp64),
+    # the fp64 sweep, and the oracle's model::AUC give the same (count_val, count_test, max) for every user - also where
+    # a candidate's score EQUALS the positive's (sums of |differences| of six-decimal parameters are multiples of 1e-6:
+    # with f64 tables some queries have such a tie, and every score is summed in the reference's order, from beta, k ascending)
     _, counts, _ = e.eval()
+    assert e.kernel_stats(4)[1] == 1
+    e.set_option("eval_screen", 0)
+    try:
+        _, counts64, _ = e.eval()
+        assert e.kernel_stats(4)[1] == 0
+    finally:
+        e.set_option("eval_screen", 1)
+    assert np.array_equal(counts, counts64)
+    _, cref = o.eval(W)
+    assert np.array_equal(counts[valid], cref[valid])
     rank = counts[valid, 2:3] - counts[valid, 0:2]
     pos = np.stack([o.val_item[valid], o.test_item[valid]], 1)
     assert np.array_equal((items == pos[:, :, None]).any(2), rank < 50)
@@ -262,6 +276,16 @@ def test_l1_top50_out_of_the_sweep_match_oracle_and_score_matrix(prec):
     for a, u in enumerate(users):
         for ctx in (0, 1):
             assert _check_topk(o.score_row(Z, int(u), ctx), items[a, ctx], scores[a, ctx], 50)
+    # ... and every column is undecided for the integer screen: the fp64 sweep answers, with the oracle's counts
+    _, counts, _ = e.eval()
+    assert e.kernel_stats(4)[1] == 2
+    _, cref = o.eval(Z)
+    assert np.array_equal(counts[valid], cref[valid])
+    # a table entry that is not finite: the screen declines, the fp64 sweep counts as the oracle does
+    Wn = W.copy(); Wn[-3] = np.inf
+    e.upload(Wn)
+    _, counts, _ = e.eval()
+    assert e.kernel_stats(4)[1] == 2
     e.close()
 
 

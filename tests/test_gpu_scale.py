@@ -198,8 +198,15 @@ def test_full_shape_l1_top50_lists_out_of_the_sweep(corpus):
     W1 = eng.download()
     assert np.isfinite(W1).all()
     m, counts, _ = eng.eval()
+    assert _screen_held(eng)                      # the sweep on fixed-point operands, no list of undecided columns overflowed
     n_all = int(m.n_users)
     assert n_all == ue - ub
+    eng.set_option("eval_screen", 0)
+    try:
+        _, counts64, _ = eng.eval()               # the fp64 sweep
+    finally:
+        eng.set_option("eval_screen", 1)
+    assert np.array_equal(counts, counts64)
     items, scores = eng.eval_topk(n_all, 50)
     assert eng.kernel_stats(5)[1] == 2 * n_all
     mine = np.arange(ub, ue)
@@ -214,6 +221,8 @@ def test_full_shape_l1_top50_lists_out_of_the_sweep(corpus):
     for u in users:
         for ctx in (0, 1):
             _check_topk(o.score_row(W1, int(u), ctx), items[u - ub, ctx], scores[u - ub, ctx], 50)
+    _, cref = o.eval(W1, nthreads=min(16, os.cpu_count() or 1))
+    assert np.array_equal(counts[users], cref[users])
     few = np.linspace(ub, ue - 1, 96).astype(np.int32)
     eng.set_option("topk_fused", 0)
     try:
