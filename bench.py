@@ -572,7 +572,7 @@ def main():
                                 "users_per_sec_with_copy_to_host": round(n_eval / tt_, 1), "device_ms": round(dev_ms, 2),
                                 "seconds_with_copy_to_host": round(tt_, 4), "lists_from_the_fused_sweep": int(lists),
                                 "lists": 2 * n_mine, "k": 50,
-                                "what": ("queries, fp64 |.|_1 sweep with a running 50th-best bar per (user, context), exact ordering of the listed; the host copy is 400 bytes of item ids per user"
+                                "what": ("queries, |.|_1 sweep on fixed-point operands (one v_sad_u32 per term) with a running 50th-best bar per (user, context), fp64 rescoring and exact ordering of the listed; the host copy is 400 bytes of item ids per user"
                                          if args.model == "TransRec_L1" else
                                          "queries, f16 sweep with a running 50th-best bar per (user, context), fp64 rescoring and exact ordering of the survivors; the host copy is 400 bytes of item ids per user")}
         del items50

@@ -173,8 +173,10 @@ int rec_eval_sampled(rec_engine* e, int topn, int32_t n_sampled, uint64_t seed, 
  * With f32 tables and k <= 64 the lists come out of the full-catalog sweep itself: every query keeps the columns whose
  * 16-bit-pipe score is within a proven bound of its running k-th best (one wavefront selects per query), the survivors
  * are scored in fp64 and ordered exactly - any number of users, no score matrix ("topk_fused" 1, the default).
- * TransRec_L1 (either table precision, k <= 64, K <= 160): its |.|_1 sweep computes the exact fp64 scores, so a query's
- * list holds (score, item) against its running k-th best, appended to and selected from by the wavefront that scores it.
+ * TransRec_L1 (either table precision, k <= 64, K <= 160): a query's list holds (score, item) against its running k-th
+ * best, appended to and selected from by the wavefront that scores it - scores of the |.|_1 sweep on fixed-point operands
+ * (one v_sad_u32 per term, within a proven bound of the exact ones; what the lists still hold at the end is scored in fp64),
+ * or the exact fp64 scores of the fp64 sweep ("eval_screen" 0, operands that are not finite).
  * Otherwise (f64 tables, k > 64, MostPopular, "topk_fused" 0, or a query with more near-ties than its list holds) the
  * scores of a batch of users are written out [rows][n_items] in fp64 and selected from there. */
 int rec_eval_topk(rec_engine* e, const int32_t* users, int32_t n_users, int32_t k, int32_t* items_out, double* scores_out);

@@ -17,6 +17,7 @@
 #include <string.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 #include <vector>
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -1161,11 +1162,14 @@ struct TopkL1Dev {
     double* scores_out;         // [nq][k]
 };
 
-// n: entries in the list of query qi (wave-uniform); returns the new bar
-__device__ __forceinline__ double l1_list_select(const TopkL1Dev& tk, int64_t qi, int& n, int lane)
+// n: entries in the list of query qi (wave-uniform); returns the new bar.  slack: 0 when the listed scores are exact; with
+// approximate scores (each within M of the exact one) 2 M - the k entries at or above the k-th best tau are exactly >=
+// tau - M, so the exact k-th best is, and a column of the exact top k is listed at >= tau - 2 M: never refused, never dropped.
+__device__ __forceinline__ double l1_list_select(const TopkL1Dev& tk, int64_t qi, int& n, int lane, double slack)
 {
     double* cs = tk.cand_s + qi * L1_LIST; int32_t* ci = tk.cand_i + qi * L1_LIST;
-    const int user = tk.qmeta[qi].x;
+    const int4 meta = tk.qmeta[qi];
+    const int user = meta.x;
     const int32_t* clk = tk.clk_item + tk.clk_off[user]; const int nc = (int)(tk.clk_off[user + 1] - tk.clk_off[user]);
     __threadfence();                           // the appends of this wavefront have reached memory
     double sc[L1_LIST / 64]; int it[L1_LIST / 64]; uint64_t key[L1_LIST / 64];
@@ -1178,7 +1182,7 @@ __device__ __forceinline__ double l1_list_select(const TopkL1Dev& tk, int64_t qi
     }
 #pragma unroll
     for (int i = 0; i < L1_LIST / 64; i++) {
-        const bool ok = lane + 64 * i < n && !sorted_contains(clk, nc, it[i]);
+        const bool ok = lane + 64 * i < n && it[i] != meta.y && it[i] != meta.z && !sorted_contains(clk, nc, it[i]);
         key[i] = ok ? order_key(sc[i]) : 0ull;
     }
     uint64_t prefix = 0;                       // the largest v with at least k keys >= v (0: fewer than k candidates)
@@ -1190,15 +1194,15 @@ __device__ __forceinline__ double l1_list_select(const TopkL1Dev& tk, int64_t qi
         for (int i = 0; i < L1_LIST / 64; i++) c += __popcll(__ballot(key[i] >= v));
         if (c >= tk.k) prefix = v;
     }
+    double nb = prefix ? order_unkey(prefix) - slack : -INFINITY;
     int off = 0;
 #pragma unroll
     for (int i = 0; i < L1_LIST / 64; i++) {
-        const bool keep = key[i] != 0ull && key[i] >= prefix;
+        const bool keep = key[i] != 0ull && sc[i] >= nb;
         const unsigned long long bal = __ballot(keep);
         if (keep) { const int at = off + __popcll(bal & ((1ull << lane) - 1ull)); cs[at] = sc[i]; ci[at] = it[i]; }
         off += __popcll(bal);
     }
-    double nb = prefix ? order_unkey(prefix) : -INFINITY;
     if (off > L1_LIST - 64) {
         if (lane == 0) tk.q_over[qi] = 1;
         off = 0; nb = INFINITY;
@@ -1338,7 +1342,7 @@ __global__ void __launch_bounds__(256) score_count_l1_kernel(EvalDev ev, const T
                 for (int a = 0; a < QPT; a++) {
                     int n = (int)sw[2 * a];
                     if (n > L1_LIST - 64) {
-                        const double nb = l1_list_select(tk, qbase + qg + NG * a, n, jj);
+                        const double nb = l1_list_select(tk, qbase + qg + NG * a, n, jj, 0.0);
                         if (jj == 0) { sw[2 * a] = (double)n; sw[2 * a + 1] = nb; }
                     }
                 }
@@ -1459,18 +1463,27 @@ __global__ void __launch_bounds__(256) l1_quant_queries_kernel(EvalDev ev, int K
 
 // a block owns QT queries for the whole catalog (tiles of 64 items through LDS, the next tile requested while the current
 // one is scored); a wavefront is 64 items against QT / 4 queries, which arrive through scalar loads
-template <int QT>
+// LISTS: top-k lists instead of counts.  A list holds (v, item), v = -(S' + B_j) the score in units of delta, within M of
+// the exact one; the bar follows the k-th best v at a distance of 2 M (l1_list_select), and topk_l1_finish_kernel scores
+// what is left in the lists in fp64.
+template <int QT, bool LISTS>
 __global__ void __launch_bounds__(256) score_count_l1_sad_kernel(EvalDev ev, const uint32_t* __restrict__ Hi, const uint32_t* __restrict__ Qi,
-                                                                 const double* __restrict__ Bj, const double* __restrict__ Tq, int I, int K, double M)
+                                                                 const double* __restrict__ Bj, const double* __restrict__ Tq, int I, int K, double M,
+                                                                 typename std::conditional<LISTS, TopkL1Dev, int>::type tk)
 {
     constexpr int TI = 64, NG = 4, QPT = QT / NG, PF = 16;
-    extern __shared__ uint32_t tile_u[];          // [TI][STR]
+    extern __shared__ uint32_t tile_u[];          // [TI][STR], then (LISTS) two doubles per query
     const int STR = K | 1;
     const int tid = threadIdx.x, jj = tid & 63, qg = tid >> 6;
     const int64_t qbase = (int64_t)blockIdx.x * QT;
     double tq[QPT]; int cnt[QPT], open[QPT];
 #pragma unroll
-    for (int a = 0; a < QPT; a++) { tq[a] = Tq[qbase + qg + NG * a]; cnt[a] = 0; open[a] = 0; }
+    for (int a = 0; a < QPT; a++) {
+        // LISTS: tq is the bar of the list (a padding row lists nothing), cnt its length
+        if constexpr (LISTS) tq[a] = tk.qmeta[qbase + qg + NG * a].x >= 0 ? -INFINITY : INFINITY;
+        else tq[a] = Tq[qbase + qg + NG * a];
+        cnt[a] = 0; open[a] = 0;
+    }
     uint32_t pre[PF]; int lofs[PF];
 #pragma unroll
     for (int e = 0; e < PF; e++) { const int i = tid + 256 * e; lofs[e] = i < TI * K ? (i / K) * STR + i % K : -1; pre[e] = 0; }
@@ -1520,6 +1533,44 @@ __global__ void __launch_bounds__(256) score_count_l1_sad_kernel(EvalDev ev, con
         }
         const bool inr = j < I;
         const double bj = inr ? Bj[j] : 0.0;
+        if constexpr (LISTS) {
+            bool crowded = false;
+#pragma unroll
+            for (int a = 0; a < QPT; a++) {
+                const double v = -((double)acc[a] + bj) + 0.0;
+                const bool in = inr && v >= tq[a];
+                const unsigned long long bal = __ballot(in);
+                if (bal) {
+                    const int64_t qi = qbase + qg + NG * a;
+                    if (in) {
+                        const int at = cnt[a] + __popcll(bal & ((1ull << jj) - 1ull));
+                        tk.cand_s[qi * L1_LIST + at] = v; tk.cand_i[qi * L1_LIST + at] = j;
+                    }
+                    cnt[a] += __popcll(bal);
+                    crowded |= cnt[a] > L1_LIST - 64;
+                }
+            }
+            if (crowded) {      // one copy of the selection code, counts and bars through LDS (as in score_count_l1_kernel)
+                double* sw = reinterpret_cast<double*>(tile_u + ((TI * STR + 1) & ~1)) + qg * (2 * QPT);
+                if (jj == 0) {
+#pragma unroll
+                    for (int a = 0; a < QPT; a++) { sw[2 * a] = (double)cnt[a]; sw[2 * a + 1] = tq[a]; }
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+                for (int a = 0; a < QPT; a++) {
+                    int n = (int)sw[2 * a];
+                    if (n > L1_LIST - 64) {
+                        const double nb = l1_list_select(tk, qbase + qg + NG * a, n, jj, 2.0 * M);
+                        if (jj == 0) { sw[2 * a] = (double)n; sw[2 * a + 1] = nb; }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int a = 0; a < QPT; a++) { cnt[a] = (int)sw[2 * a]; tq[a] = sw[2 * a + 1]; }
+            }
+            continue;
+        }
 #pragma unroll
         for (int a = 0; a < QPT; a++) {
             const double y = (double)acc[a] + bj + tq[a];
@@ -1533,6 +1584,11 @@ __global__ void __launch_bounds__(256) score_count_l1_sad_kernel(EvalDev ev, con
                 open[a] += __popcll(bal);
             }
         }
+    }
+    if constexpr (LISTS) {
+#pragma unroll
+        for (int a = 0; a < QPT; a++) if (jj == 0) tk.cand_cnt[qbase + qg + NG * a] = cnt[a];
+        return;
     }
 #pragma unroll
     for (int a = 0; a < QPT; a++) {
@@ -2056,8 +2112,8 @@ static int eval_impl(const DevModel& m, int32_t* counts_host, double* xpos_host,
                                (const unsigned*)bnd, Hi, Bj, ev.amb_overflow);
             hipLaunchKernelGGL(l1_quant_queries_kernel, dim3(2048), dim3(256), 0, st, ev, m.K, (const unsigned*)bnd, Qi, Tq);
             const size_t lds_bytes = sizeof(uint32_t) * (size_t)64 * (m.K | 1);
-            hipLaunchKernelGGL((score_count_l1_sad_kernel<L1_QT>), dim3((unsigned)(ev.nq_pad / L1_QT)), dim3(256), lds_bytes, st, ev, (const uint32_t*)Hi,
-                               (const uint32_t*)Qi, (const double*)Bj, (const double*)Tq, I, m.K, 1.0002 * m.K + 2.0);
+            hipLaunchKernelGGL((score_count_l1_sad_kernel<L1_QT, false>), dim3((unsigned)(ev.nq_pad / L1_QT)), dim3(256), lds_bytes, st, ev, (const uint32_t*)Hi,
+                               (const uint32_t*)Qi, (const double*)Bj, (const double*)Tq, I, m.K, 1.0002 * m.K + 2.0, 0);
             EV_TRY(hipGetLastError());
             int32_t over2[2] = {0, 0};
             EV_TRY(hipMemcpyAsync(over2, ev.amb_overflow, sizeof over2, hipMemcpyDeviceToHost, st));
@@ -2982,7 +3038,10 @@ static int topk_fused_impl(const DevModel& m0, const int32_t* users_host, int n_
 
 // One wavefront per query of the |.|_1 sweep: clicked items out of what the list still holds, the context's positive in
 // with the score the reference formula gives it, ordered by (score descending, item id ascending).
-__global__ void __launch_bounds__(256) topk_l1_finish_kernel(DevModel m, EvalDev ev, TopkL1Dev tk)
+// rescore: the lists hold approximate scores (the fixed-point sweep): what they still hold is scored in fp64, summed as the
+// reference sums it (from b_j, k ascending; four items per step, 16 lanes each, as in correct_clicked_kernel).
+template <class T>
+__global__ void __launch_bounds__(256) topk_l1_finish_kernel(DevModel m, EvalDev ev, TopkL1Dev tk, int rescore)
 {
     __shared__ int s_item[4][L1_LIST + 1];
     __shared__ double s_score[4][L1_LIST + 1];
@@ -3005,10 +3064,28 @@ __global__ void __launch_bounds__(256) topk_l1_finish_kernel(DevModel m, EvalDev
         const int idx = i0 + lane;
         const int item = idx < n ? ci[idx] : -1;
         const double sc = idx < n ? cs[idx] : 0.0;
-        const bool keep = idx < n && !sorted_contains(clk, nc, item);
+        const bool keep = idx < n && item != meta.y && item != meta.z && !sorted_contains(clk, nc, item);
         const unsigned long long bal = __ballot(keep);
         if (keep) { const int at = ns + __popcll(bal & ((1ull << lane) - 1ull)); s_item[wv][at] = item; s_score[wv][at] = sc; }
         ns += __popcll(bal);
+    }
+    if (rescore) {
+        __builtin_amdgcn_wave_barrier();
+        const int l16 = lane & 15, gq = lane >> 4, K = ev.K1;
+        const double* q = ev.Q + (int64_t)w * ev.KQ;
+        const T* H = (const T*)m.tab[ev.seg0];
+        for (int base = 0; base < ns; base += 4) {
+            const int idx = base + gq;
+            const int64_t ec = idx < ns ? s_item[wv][idx] : 0;
+            double pr = ev.bconst[ec];
+            for (int k0 = 0; k0 < K; k0 += 16) {
+                const int k = k0 + l16;
+                const double t = k < K ? fabs(q[k] - (double)H[ec * K + k]) : 0.0;
+                const int nn = min(16, K - k0);
+                for (int l = 0; l < nn; l++) pr += __shfl(t, (lane & 48) + l, 64);
+            }
+            if (l16 == 0 && idx < ns) s_score[wv][idx] = -pr + 0.0;
+        }
     }
     if (lane == 0) { s_item[wv][ns] = meta.y; s_score[wv][ns] = ev.thr[w]; }
     const int nt = ns + 1;
@@ -3062,6 +3139,15 @@ static int topk_l1_impl(const DevModel& m0, const int32_t* users_host, int n_use
     TL_TRY(alloc((void**)&tk.q_over, sizeof(int32_t) * max_rows));
     TL_TRY(alloc((void**)&tk.items_out, sizeof(int32_t) * (size_t)batch_users * 2 * k));
     TL_TRY(alloc((void**)&tk.scores_out, sizeof(double) * (size_t)batch_users * 2 * k));
+    uint32_t *Hi = nullptr, *Qi = nullptr; double *Bj = nullptr, *Tq = nullptr; unsigned* bnd = nullptr; int32_t* flags = nullptr;
+    if (g_screen_on) {
+        TL_TRY(alloc((void**)&Hi, sizeof(uint32_t) * (size_t)I * m.K));
+        TL_TRY(alloc((void**)&Qi, sizeof(uint32_t) * (size_t)max_rows * m.K));
+        TL_TRY(alloc((void**)&Bj, sizeof(double) * (size_t)I));
+        TL_TRY(alloc((void**)&Tq, sizeof(double) * (size_t)max_rows));
+        TL_TRY(alloc((void**)&bnd, sizeof(unsigned)));
+        TL_TRY(alloc((void**)&flags, sizeof(int32_t) * 2));
+    }
     tk.qmeta = qmeta;
     ev.col_b = ev.bconst; ev.n_cols = I;
     hipLaunchKernelGGL(item_consts_kernel<T>, dim3(blocks_for_waves(I)), dim3(256), 0, st, m, ev);
@@ -3081,8 +3167,27 @@ static int topk_l1_impl(const DevModel& m0, const int32_t* users_host, int n_use
         TL_TRY(hipMemsetAsync(tk.q_over, 0, sizeof(int32_t) * ev.nq_pad, st));
         hipLaunchKernelGGL(topk_meta_kernel, dim3((ev.nq_pad + 255) / 256), dim3(256), 0, st, m, ev, qmeta);
         hipLaunchKernelGGL(build_queries_kernel<T>, dim3(blocks_for_waves(ev.nq)), dim3(256), 0, st, m, ev);
-        if (int rc = launch_score_l1<T, 2>(ev, (const T*)m.tab[TR_H], nullptr, nullptr, I, m.K, st, tk)) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); release(); return rc; }
-        hipLaunchKernelGGL(topk_l1_finish_kernel, dim3(blocks_for_waves(ev.nq)), dim3(256), 0, st, m, ev, tk);
+        // the sweep on fixed-point operands (approximate scores in the lists, rescored in fp64 by the finish); operands that
+        // are not finite, or "eval_screen" 0: the fp64 sweep, whose lists hold the exact scores
+        int32_t declined = 1;
+        if (g_screen_on) {
+            TL_TRY(hipMemsetAsync(flags, 0, sizeof(int32_t) * 2, st));
+            TL_TRY(hipMemsetAsync(bnd, 0, sizeof(unsigned), st));
+            const int f64 = sizeof(T) == 8;
+            hipLaunchKernelGGL(l1_absmax_kernel, dim3(1024), dim3(256), 0, st, (const void*)m.tab[TR_H], f64, (int64_t)I * m.K, (const double*)ev.Q,
+                               (int64_t)ev.nq_pad * ev.KQ, bnd);
+            hipLaunchKernelGGL(l1_quant_items_kernel, dim3(2048), dim3(256), 0, st, (const void*)m.tab[TR_H], f64, I, m.K, (const double*)ev.col_b,
+                               (const unsigned*)bnd, Hi, Bj, flags);
+            hipLaunchKernelGGL(l1_quant_queries_kernel, dim3(2048), dim3(256), 0, st, ev, m.K, (const unsigned*)bnd, Qi, Tq);
+            TL_TRY(hipMemcpyAsync(&declined, flags + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            TL_TRY(hipStreamSynchronize(st));
+        }
+        if (!declined) {
+            const size_t lds_bytes = sizeof(uint32_t) * (((size_t)64 * (m.K | 1) + 1) & ~(size_t)1) + sizeof(double) * 2 * QT;
+            hipLaunchKernelGGL((score_count_l1_sad_kernel<QT, true>), dim3((unsigned)(ev.nq_pad / QT)), dim3(256), lds_bytes, st, ev, (const uint32_t*)Hi,
+                               (const uint32_t*)Qi, (const double*)Bj, (const double*)Tq, I, m.K, 1.0002 * m.K + 2.0, tk);
+        } else if (int rc = launch_score_l1<T, 2>(ev, (const T*)m.tab[TR_H], nullptr, nullptr, I, m.K, st, tk)) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); release(); return rc; }
+        hipLaunchKernelGGL(topk_l1_finish_kernel<T>, dim3(blocks_for_waves(ev.nq)), dim3(256), 0, st, m, ev, tk, declined ? 0 : 1);
         TL_TRY(hipGetLastError());
         TL_TRY(hipEventRecord(e1, st));
         over_host.resize(ev.nq);

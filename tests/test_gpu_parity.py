@@ -259,6 +259,14 @@ def test_l1_top50_out_of_the_sweep_match_oracle_and_score_matrix(prec):
     sub = valid[3:900:5]
     i2, s2 = e.eval_topk(sub, 50)
     assert np.array_equal(i2, items[3:900:5]) and np.array_equal(s2, scores[3:900:5])
+    # the lists above came out of the sweep on fixed-point operands (rescored in fp64); out of the fp64 sweep they are the same
+    e.set_option("eval_screen", 0)
+    try:
+        i4, s4 = e.eval_topk(sub, 50)
+        assert e.kernel_stats(5)[1] == 2 * len(sub)
+    finally:
+        e.set_option("eval_screen", 1)
+    assert np.array_equal(i4, i2) and np.array_equal(s4, s2)
     e.set_option("topk_fused", 0)
     try:
         i3, s3 = e.eval_topk(sub, 50)
