@@ -3189,8 +3189,23 @@ static int topk_l1_impl(const DevModel& m0, const int32_t* users_host, int n_use
         } else if (int rc = launch_score_l1<T, 2>(ev, (const T*)m.tab[TR_H], nullptr, nullptr, I, m.K, st, tk)) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); release(); return rc; }
         hipLaunchKernelGGL(topk_l1_finish_kernel<T>, dim3(blocks_for_waves(ev.nq)), dim3(256), 0, st, m, ev, tk, declined ? 0 : 1);
         TL_TRY(hipGetLastError());
-        TL_TRY(hipEventRecord(e1, st));
         over_host.resize(ev.nq);
+        if (!declined) {
+            // A list that could not hold the columns within two margins of its k-th best (operands with an outlier far above the
+            // rest leave the fixed-point scale too coarse to tell the others apart): the batch again through the fp64 sweep,
+            // whose lists only overflow on exact ties.
+            TL_TRY(hipMemcpyAsync(over_host.data(), tk.q_over, sizeof(int32_t) * ev.nq, hipMemcpyDeviceToHost, st));
+            TL_TRY(hipStreamSynchronize(st));
+            bool any = false;
+            for (int32_t x : over_host) any |= x != 0;
+            if (any) {
+                TL_TRY(hipMemsetAsync(tk.q_over, 0, sizeof(int32_t) * ev.nq_pad, st));
+                if (int rc = launch_score_l1<T, 2>(ev, (const T*)m.tab[TR_H], nullptr, nullptr, I, m.K, st, tk)) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); release(); return rc; }
+                hipLaunchKernelGGL(topk_l1_finish_kernel<T>, dim3(blocks_for_waves(ev.nq)), dim3(256), 0, st, m, ev, tk, 0);
+                TL_TRY(hipGetLastError());
+            }
+        }
+        TL_TRY(hipEventRecord(e1, st));
         TL_TRY(hipMemcpyAsync(over_host.data(), tk.q_over, sizeof(int32_t) * ev.nq, hipMemcpyDeviceToHost, st));
         TL_TRY(hipMemcpyAsync(items_host + (size_t)u0 * 2 * k, tk.items_out, sizeof(int32_t) * (size_t)nu * 2 * k, hipMemcpyDeviceToHost, st));
         if (scores_host) TL_TRY(hipMemcpyAsync(scores_host + (size_t)u0 * 2 * k, tk.scores_out, sizeof(double) * (size_t)nu * 2 * k, hipMemcpyDeviceToHost, st));

@@ -275,6 +275,22 @@ def test_l1_top50_out_of_the_sweep_match_oracle_and_score_matrix(prec):
         e.set_option("topk_fused", 1)
     assert np.allclose(s3, s2, rtol=1e-12, atol=1e-12)
     assert (i3 == i2).mean() > 0.99
+    # one item row far outside the range of the others: the fixed-point scale is too coarse to tell the others apart - counts
+    # come from the fp64 sweep (the screen's lists overflow) and the lists from the fp64 sweep's exact lists, not the score matrix
+    Wo = W.copy()
+    Wo[o.n_items + 7 * int(g["K"]): o.n_items + 8 * int(g["K"])] = 3.0e7 if prec == F32 else 3.0e9      # row 7 of H
+    e.upload(Wo)
+    _, c_o, _ = e.eval()
+    assert e.kernel_stats(4)[1] == 2
+    _, cref = o.eval(Wo)
+    assert np.array_equal(c_o[valid], cref[valid])
+    few = valid[:40]
+    i5, s5 = e.eval_topk(few, 50)
+    assert e.kernel_stats(5)[1] == 2 * len(few)
+    for a, u in enumerate(few[:8]):
+        for ctx in (0, 1):
+            _check_topk(o.score_row(Wo, int(u), ctx), i5[a, ctx], s5[a, ctx], 50)
+    e.upload(W)
     # all-zero tables: every candidate ties, no list can hold them, the score-matrix path answers (lowest item ids first)
     Z = np.zeros(e.nw)
     e.upload(Z)
