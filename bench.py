@@ -590,7 +590,7 @@ def main():
             variants[name] = {"triples_per_sec": r["value"], "ms_per_step": r["ms_per_step"], "update": r["update"], "roofline": r["roofline"]}
 
         if mode["policy"] == 1 and not mode["owner"]:
-            # options that trade fidelity for fewer float atomics (accuracy of each: DESIGN.md)
+            # options that trade fidelity for fewer float atomics (what each costs in accuracy: tests/test_gpu_mid.py)
             variant("pairs_share_negative", {"share_negative": 2}, dict(mode, neg_share=2))
             variant("plain_stores", {"share_negative": 1, "update_policy": 2}, dict(mode, policy=2))
             eng.set_option("update_policy", 1)
